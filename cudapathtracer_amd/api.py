@@ -1,0 +1,342 @@
+"""ctypes binding of ``libptamd.so`` (C ABI: ``include/pt_api.h``).
+
+Python is plumbing here, not the product: every function below is a thin call into the HIP
+library. There is NO CPU fallback — loading fails loudly if the library is missing, and every
+render fails loudly without a HIP device.
+
+Mirrors the reference's names where it has them: ``launch_unidirectional`` /
+``launch_naive_unidirectional`` (deviceCode.cuh:8-12), ``init_render`` (main.cu:235),
+``Camera.Pinhole`` / ``NotPinhole`` (objects.cuh:221-264).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libptamd.so")
+
+UNIDIRECTIONAL = 0
+NAIVE_UNIDIRECTIONAL = 2
+SEED = 103033  # deviceCode.cu:552
+INFO_KEYS = ("width", "height", "spp", "max_depth", "integrator", "leaf_size", "n_tris", "n_lights", "n_nodes",
+             "n_points", "n_normals", "n_uvs", "n_mats", "largest_leaf", "backup_count", "tree_depth")
+COUNTER_KEYS = ("rays_closest", "rays_shadow", "node_pops", "box_tests", "tri_tests", "hits", "rng_draws", "iterations")
+
+
+class _F4(C.Union):  # pt_float4: 16 bytes, 16-byte aligned (the long double member only forces the alignment)
+    _fields_ = [("v", C.c_float * 4), ("_align", C.c_longdouble)]
+
+
+class Camera(C.Structure):
+    """pt_camera == the reference's Camera (objects.cuh:199-219), 112 bytes."""
+
+    _fields_ = [("cameraOrigin", _F4), ("w", C.c_int32), ("h", C.c_int32), ("xRot", C.c_float), ("yRot", C.c_float),
+                ("zRot", C.c_float), ("aperture", C.c_float), ("focalDist", C.c_float), ("fovScale", C.c_float),
+                ("antiAliasJitterDist", C.c_float), ("_pad", C.c_float * 3), ("forward", _F4), ("right", _F4), ("up", _F4)]
+
+    @staticmethod
+    def Pinhole(pos, w, h, rot=(0.0, 0.0, 0.0), fov=60.0):
+        return make_camera(True, pos, rot, fov, w, h)
+
+    @staticmethod
+    def NotPinhole(pos, w, h, rot, fov, aperture, focal_dist):
+        return make_camera(False, pos, rot, fov, w, h, aperture, focal_dist)
+
+    def tobytes(self):
+        return bytes(memoryview(self))
+
+    @staticmethod
+    def frombytes(b):
+        return Camera.from_buffer_copy(bytes(b))
+
+
+assert C.sizeof(Camera) == 112 and C.alignment(Camera) == 16
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("n_positions", C.c_int32), ("normals", C.c_void_p), ("n_normals", C.c_int32),
+                ("uvs", C.c_void_p), ("n_uvs", C.c_int32), ("triangles", C.c_void_p), ("n_triangles", C.c_int32),
+                ("lights", C.c_void_p), ("n_lights", C.c_int32), ("bvh", C.c_void_p), ("n_nodes", C.c_int32),
+                ("bvh_indices", C.c_void_p), ("materials", C.c_void_p), ("n_materials", C.c_int32),
+                ("textures", C.c_void_p), ("n_texels", C.c_int32)]
+
+
+class TileRange(C.Structure):
+    _fields_ = [("first", C.c_int32), ("stride", C.c_int32), ("count", C.c_int32)]
+
+
+class PtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libptamd.so; raise if it was not built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtError("%s is missing: build it with `make -C cudapathtracer_amd/csrc` (or __graft_entry__.build()); "
+                      "this package has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_float
+    L.pt_api_version.restype = i32
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_device_count.restype = i32
+    L.pt_scene_create.restype = vp; L.pt_scene_create.argtypes = [C.POINTER(SceneDesc)]
+    L.pt_scene_destroy.argtypes = [vp]
+    L.pt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, C.POINTER(TileRange), vp]
+    L.pt_render_counted.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, C.POINTER(TileRange), vp, vp]
+    L.pt_render_tiles_device.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, C.POINTER(TileRange), vp, i32, vp]
+    L.pt_untile_device.argtypes = [i32, i32, C.POINTER(TileRange), vp, vp, vp]
+    L.pt_tile_device.argtypes = [i32, i32, C.POINTER(TileRange), vp, vp, vp]
+    L.pt_launch_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
+    L.pt_launch_naive_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
+    L.pt_get_counters.argtypes = [vp, vp]
+    L.pt_reset_counters.argtypes = [vp]
+    L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
+    L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
+    L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.pt_probe_camera_rays.argtypes = [C.POINTER(Camera), u64, i32, vp, vp]
+    L.pt_probe_trace_closest.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pt_probe_trace_shadow.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pt_probe_bsdf_sample.argtypes = [vp, i32, vp, vp, vp, f32, f32, u64, vp, vp]
+    L.pt_probe_bsdf_eval.argtypes = [vp, i32, vp, vp, vp, f32, f32, vp]
+    L.novum_scene_load.restype = vp; L.novum_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32]
+    L.novum_scene_free.argtypes = [vp]
+    L.novum_scene_info.argtypes = [vp, vp]
+    L.novum_scene_desc.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.novum_scene_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.novum_make_camera.argtypes = [i32, vp, vp, f32, f32, f32, i32, i32, C.POINTER(Camera)]
+    L.novum_finalise.argtypes = [vp, i32, i32]
+    L.novum_init_render.argtypes = [C.c_char_p, C.c_char_p, i32, vp, C.c_char_p]
+    L.novum_save_bmp.argtypes = [C.c_char_p, vp, i32, i32, i32]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise PtError("%s failed (%d): %s" % (what, rc, lib().pt_last_error().decode(errors="replace")))
+
+
+def device_count():
+    return lib().pt_device_count()
+
+
+def make_camera(pinhole, pos, rot, fov, w, h, aperture=0.0, focal_dist=0.0):
+    cam = Camera()
+    pos = np.ascontiguousarray(pos, np.float32); rot = np.ascontiguousarray(rot, np.float32)
+    lib().novum_make_camera(int(pinhole), _p(pos), _p(rot), fov, aperture, focal_dist, w, h, C.byref(cam))
+    return cam
+
+
+def finalise(rgba_sum, spp):
+    """main.cu:860-870: divide by spp, NaN -> (1,0,1), Inf -> (0,1,0)."""
+    out = np.ascontiguousarray(rgba_sum, np.float32).copy()
+    lib().novum_finalise(_p(out), out.size // 4, spp)
+    return out
+
+
+def save_bmp(path, rgba, post_process=True):
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    if lib().novum_save_bmp(path.encode(), _p(rgba), w, h, int(post_process)) != 0:
+        raise PtError("could not write " + path)
+
+
+def init_render(config_path, render_number=0, base_dir=None, bmp_path=None):
+    """initRender (main.cu:235-923) for the unidirectional integrators; returns finalised [h,w,4]."""
+    hs = HostScene(config_path, base_dir, render_number)
+    w, h = hs.info["width"], hs.info["height"]
+    hs.close()
+    out = np.zeros((h, w, 4), np.float32)
+    rc = lib().novum_init_render(config_path.encode(), base_dir.encode() if base_dir else None, render_number, _p(out),
+                                 bmp_path.encode() if bmp_path else None)
+    _check(rc, "novum_init_render")
+    return out
+
+
+class HostScene:
+    """What the kept scene loader produces (novum_scene_load): host arrays in the reference's data model."""
+
+    _ARRAYS = {"points": ("positions", "n_positions", 16), "normals": ("normals", "n_normals", 16), "uvs": ("uvs", "n_uvs", 8),
+               "mesh": ("triangles", "n_triangles", 80), "lights": ("lights", "n_lights", 80), "bvh": ("bvh", "n_nodes", 48),
+               "indices": ("bvh_indices", "n_triangles", 4), "materials": ("materials", "n_materials", 176)}
+
+    def __init__(self, config_path, base_dir=None, render_number=0):
+        self.h = lib().novum_scene_load(config_path.encode(), base_dir.encode() if base_dir else None, render_number)
+        if not self.h:
+            raise PtError("novum_scene_load failed for " + config_path)
+        info = np.zeros(16, np.int32)
+        lib().novum_scene_info(self.h, _p(info))
+        self.info = dict(zip(INFO_KEYS, (int(v) for v in info)))
+        self.desc = SceneDesc()
+        lib().novum_scene_desc(self.h, C.byref(self.desc))
+
+    def camera(self):
+        cam = Camera()
+        lib().novum_scene_camera(self.h, C.byref(cam))
+        return cam
+
+    def array(self, what):
+        field, count, size = self._ARRAYS[what]
+        n = getattr(self.desc, count) * size
+        ptr = getattr(self.desc, field)
+        if not ptr or n == 0:
+            return np.zeros(0, np.uint8)
+        return np.frombuffer((C.c_uint8 * n).from_address(ptr), np.uint8).copy()
+
+    def close(self):
+        if self.h:
+            lib().novum_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """Device-resident, re-packed scene (pt_scene). Created on the CURRENT HIP device."""
+
+    def __init__(self, host: HostScene | None = None, desc: SceneDesc | None = None):
+        d = host.desc if host is not None else desc
+        self.h = lib().pt_scene_create(C.byref(d))
+        if not self.h:
+            raise PtError("pt_scene_create failed: " + lib().pt_last_error().decode(errors="replace"))
+
+    @staticmethod
+    def from_config(config_path, base_dir=None, render_number=0):
+        hs = HostScene(config_path, base_dir, render_number)
+        return Scene(hs), hs
+
+    def close(self):
+        if self.h:
+            lib().pt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- launchers ------------------------------------------------------------------------------
+    def render(self, camera, w, h, spp, max_depth, integrator=UNIDIRECTIONAL, use_mis=True, seed=SEED, tiles=None,
+               counters=False, out=None):
+        """Host-buffer launcher: returns (sum-of-samples [h,w,4] float32, per-pixel counters [h,w,8] or None)."""
+        col = np.zeros((h, w, 4), np.float32) if out is None else out
+        cnt = np.zeros((h, w, 8), np.uint32) if counters else None
+        tr = C.byref(tiles) if tiles is not None else None
+        rc = lib().pt_render_counted(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, tr, _p(col), _p(cnt))
+        _check(rc, "pt_render")
+        return col, cnt
+
+    def render_tiles_device(self, camera, w, h, spp, max_depth, d_tile_ptr, integrator=UNIDIRECTIONAL, use_mis=True,
+                            seed=SEED, tiles=None, count_work=False, stream=0):
+        tr = C.byref(tiles) if tiles is not None else None
+        rc = lib().pt_render_tiles_device(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, tr,
+                                          d_tile_ptr, int(count_work), stream or None)
+        _check(rc, "pt_render_tiles_device")
+
+    def launch_unidirectional(self, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr):
+        _check(lib().pt_launch_unidirectional(max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr), "pt_launch_unidirectional")
+
+    def launch_naive_unidirectional(self, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr):
+        _check(lib().pt_launch_naive_unidirectional(max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr), "pt_launch_naive_unidirectional")
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        _check(lib().pt_get_counters(self.h, _p(out)), "pt_get_counters")
+        return dict(zip(COUNTER_KEYS, (int(v) for v in out)))
+
+    def reset_counters(self):
+        _check(lib().pt_reset_counters(self.h), "pt_reset_counters")
+
+    def last_kernel_ms(self):
+        return float(lib().pt_last_kernel_ms(self.h))
+
+    # -- probes ---------------------------------------------------------------------------------
+    def trace_closest(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = len(rays)
+        oi = np.zeros((n, 4), np.int32); of = np.zeros((n, 12), np.float32); cnt = np.zeros(8, np.uint64)
+        _check(lib().pt_probe_trace_closest(self.h, n, _p(rays), _p(oi), _p(of), _p(cnt)), "pt_probe_trace_closest")
+        return oi, of, dict(zip(COUNTER_KEYS, (int(v) for v in cnt)))
+
+    def trace_shadow(self, rays, max_t):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        max_t = np.ascontiguousarray(max_t, np.float32)
+        n = len(rays)
+        of = np.zeros((n, 3), np.float32); cnt = np.zeros(8, np.uint64)
+        _check(lib().pt_probe_trace_shadow(self.h, n, _p(rays), _p(max_t), _p(of), _p(cnt)), "pt_probe_trace_shadow")
+        return of, dict(zip(COUNTER_KEYS, (int(v) for v in cnt)))
+
+    def bsdf_sample(self, material, wi, backface, subseq, eta_i=1.0, eta_t=1.0, seed=SEED):
+        material = np.ascontiguousarray(material, np.int32); wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+        backface = np.ascontiguousarray(backface, np.int32); subseq = np.ascontiguousarray(subseq, np.uint32)
+        n = len(material)
+        out = np.zeros((n, 8), np.float32)
+        _check(lib().pt_probe_bsdf_sample(self.h, n, _p(material), _p(wi), _p(backface), eta_i, eta_t, seed, _p(subseq), _p(out)), "pt_probe_bsdf_sample")
+        return out
+
+    def bsdf_eval(self, material, wi, wo, eta_i=1.0, eta_t=1.0):
+        material = np.ascontiguousarray(material, np.int32)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3); wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        n = len(material)
+        out = np.zeros((n, 4), np.float32)
+        _check(lib().pt_probe_bsdf_eval(self.h, n, _p(material), _p(wi), _p(wo), eta_i, eta_t, _p(out)), "pt_probe_bsdf_eval")
+        return out
+
+
+def untile_device(w, h, d_tiles_ptr, d_colors_ptr, tiles=None, stream=0):
+    _check(lib().pt_untile_device(w, h, C.byref(tiles) if tiles is not None else None, d_tiles_ptr, d_colors_ptr, stream or None), "pt_untile_device")
+
+
+def tile_device(w, h, d_colors_ptr, d_tiles_ptr, tiles=None, stream=0):
+    _check(lib().pt_tile_device(w, h, C.byref(tiles) if tiles is not None else None, d_colors_ptr, d_tiles_ptr, stream or None), "pt_tile_device")
+
+
+def n_tiles(w, h):
+    return ((w + 7) // 8) * ((h + 7) // 8)
+
+
+def rank_tiles(w, h, rank, world):
+    """Interleaved tile ownership: rank r renders tiles {t : t mod world == r}."""
+    total = n_tiles(w, h)
+    count = (total - rank + world - 1) // world if rank < total else 0
+    return TileRange(rank, world, count)
+
+
+def probe_rng(subsequences, n_draws, seed=SEED):
+    sub = np.ascontiguousarray(subsequences, np.uint32)
+    n = len(sub)
+    st = np.zeros((n, 6), np.uint32); u = np.zeros((n, max(n_draws, 1)), np.uint32); f = np.zeros((n, max(n_draws, 1)), np.float32)
+    _check(lib().pt_probe_rng(seed, n, _p(sub), n_draws, _p(st), _p(u), _p(f)), "pt_probe_rng")
+    return st, u[:, :n_draws], f[:, :n_draws]
+
+
+def probe_math(x):
+    x = np.ascontiguousarray(x, np.float32)
+    outs = [np.zeros_like(x) for _ in range(5)]
+    _check(lib().pt_probe_math(x.size, _p(x), *[_p(o) for o in outs]), "pt_probe_math")
+    return dict(zip(("sin", "cos", "exp", "rsqrt", "pow5"), outs))
+
+
+def probe_camera_rays(camera, xy, seed=SEED):
+    xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+    out = np.zeros((len(xy), 6), np.float32)
+    _check(lib().pt_probe_camera_rays(C.byref(camera), seed, len(xy), _p(xy), _p(out)), "pt_probe_camera_rays")
+    return out

@@ -1,0 +1,566 @@
+// novum_host.cpp — the host side the reference keeps around the hot path, restated in plain
+// C++ (the reference's lives in CUDA-typed .cu/.cuh files): `.rendertron` parser
+// (objects.cuh:844-943), OBJ reader (main.cu:936-1068), material table (main.cu:397-467),
+// SAH BVH builder (main.cu:20-233), camera set-up (objects.cuh:221-264, 309-325), finalise
+// (main.cu:860-870), BMP output (imageUtil.cu:69-100, 202-232) and initRender (main.cu:235-923)
+// for the two unidirectional integrators. It produces the reference's own data model
+// (pt_triangle / pt_bvh_node / pt_material ...) and hands it to pt_scene_create.
+//
+// Behaviour the reference leaves undefined is resolved as SURVEY.md Appendix D lists:
+// materials are zero-initialised before their factory runs; faces without `vn` get their
+// geometric normal, faces without `vt` get uv (0,0); the std::nth_element fallback of the
+// builder is a full sort by (centroid, index); parseVec3's .w is 0.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+
+namespace {
+
+struct F3 { float x, y, z; };
+inline pt_float4 P4(float x, float y, float z) { return pt_float4{x, y, z, 0.0f}; }
+inline float comp(const pt_float4& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+struct MeshLine { std::string path; float mult = 0.0f; float rgb[3] = {0, 0, 0}; int material = 0; };
+
+struct Config {                                   // RenderConfig, objects.cuh:801-842 (hot-path keys)
+    int width = 0, height = 0, spp = 0, maxDepth = 0, leafSize = 0;
+    std::string name, integrator;
+    bool postProcess = false, pinhole = false;
+    float camPos[3] = {0, 0, 0}, camRot[3] = {0, 0, 0};
+    float fov = 0, aperture = 0, focalDist = 0;
+    std::vector<MeshLine> meshes;
+};
+
+std::string strip(const std::string& s) {         // trim, util.cuh:288-293
+    size_t a = s.find_first_not_of(" \t\r\n");
+    if (a == std::string::npos) return s;
+    size_t b = s.find_last_not_of(" \t\r\n");
+    return s.substr(a, b - a + 1);
+}
+bool truthy(std::string v) { for (char& c : v) c = (char)tolower((unsigned char)c); return v == "true"; }   // parseBool, util.cuh:302-306
+void vec3_of(const std::string& s, float out[3]) {                                                          // parseVec3, util.cuh:295-300
+    // operator>> semantics: stop at the first token that is not a number
+    const char* p = s.c_str();
+    for (int i = 0; i < 3; i++) {
+        char* e = nullptr;
+        float v = strtof(p, &e);
+        if (e == p) return;
+        out[i] = v; p = e;
+    }
+}
+
+bool parse_config(const std::string& path, Config& c) {            // loadConfig, objects.cuh:844-943
+    std::ifstream f(path);
+    if (!f.is_open()) { fprintf(stderr, "Error: Could not open config file: %s\n", path.c_str()); return false; }
+    std::string raw;
+    bool meshes = false;
+    while (std::getline(f, raw)) {
+        std::string line = strip(raw);
+        if (line.empty()) continue;
+        if (line.compare(0, 6, "Meshes") == 0) { meshes = true; continue; }
+        if (meshes) {
+            // path; mult * (r, g, b); materialID
+            MeshLine m;
+            size_t s1 = line.find(';');
+            m.path = strip(line.substr(0, s1));
+            if (s1 != std::string::npos) {
+                size_t s2 = line.find(';', s1 + 1);
+                std::string em = strip(line.substr(s1 + 1, s2 == std::string::npos ? std::string::npos : s2 - s1 - 1));
+                size_t star = em.find('*'), lp = em.find('('), rp = em.find(')');
+                if (star != std::string::npos && lp != std::string::npos) {
+                    m.mult = std::stof(em.substr(0, star));
+                    std::string v = em.substr(lp + 1, rp - lp - 1);
+                    std::replace(v.begin(), v.end(), ',', ' ');
+                    vec3_of(v, m.rgb);
+                }
+                if (s2 != std::string::npos) {
+                    size_t s3 = line.find(';', s2 + 1);
+                    m.material = std::stoi(strip(line.substr(s2 + 1, s3 == std::string::npos ? std::string::npos : s3 - s2 - 1)));
+                }
+            }
+            c.meshes.push_back(m);
+            continue;
+        }
+        size_t colon = line.find(':');
+        if (colon == std::string::npos) continue;
+        std::string key = strip(line.substr(0, colon)), val = strip(line.substr(colon + 1));
+        if (val.empty()) continue;
+        if (key == "width") c.width = std::stoi(val);
+        else if (key == "height") c.height = std::stoi(val);
+        else if (key == "Integrator") c.integrator = val;
+        else if (key == "Name") c.name = val;
+        else if (key == "Sample Count") c.spp = std::stoi(val);
+        else if (key == "Unidirectional Max Depth") c.maxDepth = std::stoi(val);
+        else if (key == "BVH recommended leaf size") c.leafSize = std::stoi(val);
+        else if (key == "Pinhole Camera") c.pinhole = truthy(val);
+        else if (key == "Post Process") c.postProcess = truthy(val);
+        else if (key == "Camera Position") vec3_of(val, c.camPos);
+        else if (key == "Camera Rotation") vec3_of(val, c.camRot);
+        else if (key == "Camera FOV") c.fov = std::stof(val);
+        else if (key == "Camera Apeture") c.aperture = std::stof(val);
+        else if (key == "Camera FocalDist") c.focalDist = std::stof(val);
+        // every other key (BDPT / VCM settings, objects.cuh:916-939) belongs to out-of-scope integrators
+    }
+    return true;
+}
+
+int integrator_id(const std::string& n) {                           // matchIntegrator, objects.cuh:583-593
+    if (n == "UNIDIRECTIONAL") return 0;
+    if (n == "BIDIRECTIONAL" || n == "BDPT") return 1;
+    if (n == "NAIVE_UNIDIRECTIONAL") return 2;
+    if (n == "VCM") return 3;
+    if (n == "SPPM") return 4;
+    return -1;
+}
+
+}  // namespace
+
+struct novum_scene {
+    Config cfg;
+    std::vector<pt_float4> points, normals, textures;
+    std::vector<pt_float2> uvs;
+    std::vector<pt_triangle> mesh, lights;
+    std::vector<pt_bvh_node> bvh;
+    std::vector<int32_t> indices;
+    std::vector<pt_material> mats;
+    pt_camera cam{};
+    int largestLeaf = 0, backups = 0, treeDepth = 0;
+};
+
+namespace {
+
+// ---- OBJ (main.cu:936-1068) ---------------------------------------------------------------------
+struct Cursor {
+    const char* p; const char* end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) p++; }
+    bool number(double& v) { ws(); if (p >= end) return false; char* e; v = strtod(p, &e); if (e == p) return false; p = e; return true; }
+    bool token(std::string& t) { ws(); if (p >= end) return false; const char* s = p; while (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f')) p++; t.assign(s, p); return true; }
+};
+
+inline float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }      // same contract as the kernels
+inline F3 cross3(F3 a, F3 b) { return F3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))}; }
+
+void read_obj(const std::string& file, novum_scene& S, const float e[3], int materialID, const float off[3]) {
+    std::ifstream in(file, std::ios::binary);
+    if (!in.is_open()) { fprintf(stderr, "Error: Could not open OBJ file\n"); return; }
+    std::string data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const int vBase = (int)S.points.size(), nBase = (int)S.normals.size(), tBase = (int)S.uvs.size();
+    int nextLight = (int)S.lights.size();
+    int zeroUv = -1;
+    const bool isLight = dot3(F3{e[0], e[1], e[2]}, F3{e[0], e[1], e[2]}) > 0;
+    std::vector<int> vi, ti, ni;
+    std::string tok;
+    size_t pos = 0;
+    while (pos < data.size()) {
+        size_t nl = data.find('\n', pos);
+        if (nl == std::string::npos) nl = data.size();
+        Cursor c{data.data() + pos, data.data() + nl};
+        pos = nl + 1;
+        if (c.p == c.end || *c.p == '#' || *c.p == 's') continue;
+        if (!c.token(tok)) continue;
+        if (tok == "v") {
+            double x = 0, y = 0, z = 0;
+            (void)(c.number(x) && c.number(y) && c.number(z));
+            S.points.push_back(P4((float)x + off[0], (float)y + off[1], (float)z + off[2]));
+        } else if (tok == "vt") {
+            double u = 0, v = 0;
+            (void)(c.number(u) && c.number(v));
+            S.uvs.push_back(pt_float2{(float)u, (float)(1.0 - v)});
+        } else if (tok == "vn") {
+            double x = 0, y = 0, z = 0;
+            bool ok = c.number(x) && c.number(y) && c.number(z);
+            if (!ok || std::isnan(x) || std::isnan(y) || std::isnan(z)) { S.normals.push_back(P4(0, 1, 0)); continue; }
+            float fx = (float)x, fy = (float)y, fz = (float)z;
+            if (fx * fx + fy * fy + fz * fz < 1e-12f) { fx = 0; fy = 1; fz = 0; }
+            S.normals.push_back(P4(fx, fy, fz));
+        } else if (tok == "f") {
+            vi.clear(); ti.clear(); ni.clear();
+            while (c.token(tok)) {
+                // v[/vt[/vn]] — an empty field contributes no index (main.cu:1003-1017)
+                size_t a = tok.find('/');
+                std::string f0 = tok.substr(0, a), f1, f2;
+                if (a != std::string::npos) {
+                    size_t b = tok.find('/', a + 1);
+                    f1 = tok.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1);
+                    if (b != std::string::npos) { size_t d = tok.find('/', b + 1); f2 = tok.substr(b + 1, d == std::string::npos ? std::string::npos : d - b - 1); }
+                }
+                if (!f0.empty()) vi.push_back(std::stoi(f0) - 1);
+                if (!f1.empty()) ti.push_back(std::stoi(f1) - 1);
+                if (!f2.empty()) ni.push_back(std::stoi(f2) - 1);
+            }
+            const bool hasUV = ti.size() == vi.size(), hasN = ni.size() == vi.size();
+            const int n = (int)vi.size();
+            for (int i = 1; i < n - 1; ++i) {                  // fan from the first vertex
+                int i0 = vi[0] + vBase, i1 = vi[i] + vBase, i2 = vi[i + 1] + vBase;
+                const pt_float4 &p0 = S.points[i0], &p1 = S.points[i1], &p2 = S.points[i2];
+                F3 e1{p1.x - p0.x, p1.y - p0.y, p1.z - p0.z}, e2{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z};
+                F3 cp = cross3(e1, e2);
+                if (dot3(cp, cp) < 1e-18f) continue;           // degenerate-triangle cull, main.cu:1040
+                pt_triangle t;
+                std::memset(&t, 0, sizeof(t));
+                t.aInd = i0; t.bInd = i1; t.cInd = i2;
+                if (hasUV) { t.uvaInd = ti[0] + tBase; t.uvbInd = ti[i] + tBase; t.uvcInd = ti[i + 1] + tBase; }
+                else {
+                    if (zeroUv < 0) { zeroUv = (int)S.uvs.size(); S.uvs.push_back(pt_float2{0.0f, 0.0f}); }
+                    t.uvaInd = t.uvbInd = t.uvcInd = zeroUv;
+                }
+                if (hasN) { t.naInd = ni[0] + nBase; t.nbInd = ni[i] + nBase; t.ncInd = ni[i + 1] + nBase; }
+                else {
+                    float il = 1.0f / sqrtf(dot3(cp, cp));
+                    t.naInd = t.nbInd = t.ncInd = (int)S.normals.size();
+                    S.normals.push_back(P4(cp.x * il, cp.y * il, cp.z * il));
+                }
+                t.materialID = materialID;
+                t.emission = P4(e[0], e[1], e[2]);
+                t.lightInd = isLight ? nextLight : -51;
+                t.triInd = (int)S.mesh.size();
+                S.mesh.push_back(t);
+                if (isLight) { S.lights.push_back(t); nextLight++; }
+            }
+        }
+    }
+}
+
+// ---- materials (objects.cuh:640-791, main.cu:397-467) -------------------------------------------
+pt_material base_material() {
+    pt_material m;
+    std::memset(&m, 0, sizeof(m));
+    m.type = PT_MAT_DIFFUSE; m.albedo = P4(0.8f, 0.8f, 0.8f); m.roughness = 0.5f; m.ior = 1.5f; m.specular = 1.0f;
+    return m;
+}
+pt_material lambert(float r, float g, float b) { pt_material m = base_material(); m.albedo = P4(r, g, b); m.roughness = 1.0f; return m; }
+pt_material lambert_tex(int start, int w, int h) { pt_material m = base_material(); m.hasTexture = 1; m.startInd = start; m.width = w; m.height = h; m.roughness = 1.0f; return m; }
+pt_material conductor(pt_float4 eta, pt_float4 k, float rough) {
+    pt_material m = base_material();
+    m.type = PT_MAT_METAL; m.eta = eta; m.k = k; m.roughness = rough; m.albedo = P4(1, 1, 1); m.metallic = 1.0f;
+    return m;
+}
+pt_material glassy(float ior, pt_float4 absorb, int priority) {
+    pt_material m = base_material();
+    m.type = PT_MAT_SMOOTHDIELECTRIC; m.ior = ior; m.albedo = P4(1, 1, 1); m.priority = priority; m.isSpecular = 1; m.boundary = 1; m.absorption = absorb;
+    return m;
+}
+pt_material leafy(int start, int w, int h, float ior, float rough, pt_float4 albedo, float transmission) {
+    pt_material m = base_material();
+    m.type = PT_MAT_LEAF; m.hasTexture = 1; m.ior = ior; m.roughness = rough; m.albedo = albedo; m.transmission = transmission;
+    m.startInd = start; m.width = w; m.height = h; m.thinWalled = 1;
+    return m;
+}
+pt_material mirror_mat() { pt_material m = base_material(); m.type = PT_MAT_DELTAMIRROR; m.isSpecular = 1; return m; }
+
+void material_table(novum_scene& S, const int texStart[4], const int texW[4], const int texH[4]) {
+    pt_float4 etaSteel{0.14f, 0.16f, 0.13f, 1.0f}, etaGold = P4(0.17f, 0.35f, 1.5f);
+    pt_float4 teaAbs = P4(2.5f * 0.180f, 2.5f * 1.5f, 2.5f * 2.996f);
+    pt_float4 leafGreen = P4(0.22f, 0.75f, 0.28f);
+    S.mats = {
+        glassy(1.0f, P4(0, 0, 0), 99),                               // 0 air
+        lambert(0.4f, 0.4f, 0.8f),                                   // 1 blue
+        lambert(0.9f, 0.9f, 0.9f),                                   // 2 white
+        lambert(0.2f, 0.6f, 0.6f),                                   // 3 teal
+        conductor(etaGold, etaGold, 0.05f),                          // 4 gold (k := eta, main.cu:419)
+        glassy(1.5f, P4(0, 0, 0), 1),                                // 5 glass
+        lambert(0.90f, 0.1f, 0.1f),                                  // 6 red
+        conductor(etaSteel, etaSteel, 0.15f),                        // 7 steel
+        glassy(1.333f, teaAbs, 2),                                   // 8 tea
+        glassy(1.31f, P4(0.2f, 0.2f, 0.2f), 0),                      // 9 ice
+        glassy(1.333f, P4(0, 0, 0), 2),                              // 10 water
+        lambert_tex(texStart[0], texW[0], texH[0]),                  // 11
+        lambert_tex(texStart[1], texW[1], texH[1]),                  // 12
+        leafy(texStart[2], texW[2], texH[2], 1.5f, 0.10f, leafGreen, 0.15f),   // 13 leaf
+        lambert(0.90f, 0.9f, 0.83f),                                 // 14 stem
+        lambert(0.4f, 0.4f, 1.00f),                                  // 15 sky
+        leafy(texStart[3], texW[3], texH[3], 1.5f, 0.8f, leafGreen, 0.6f),     // 16 autumn leaf
+        lambert(0.8f, 0.8f, 0.8f),                                   // 17 grey
+        glassy(2.42f, P4(0, 0, 0), 1),                               // 18 diamond
+        mirror_mat(),                                                // 19
+        lambert(0.0f, 0.0f, 0.0f),                                   // 20 black
+        lambert(0.95f, 0.95f, 0.95f),                                // 21
+        lambert(0.5f, 0.5f, 0.5f),                                   // 22
+        lambert(0.1f, 0.9f, 0.1f),                                   // 23 green
+    };
+}
+
+// ---- SAH BVH (main.cu:20-233), iterative, same pre-order numbering ---------------------------------
+struct Builder {
+    novum_scene& S;
+    std::vector<pt_float4> cen, lo, hi;
+    int leafMax;
+    static pt_float4 vmin(const pt_float4& a, const pt_float4& b) { return P4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+    static pt_float4 vmax(const pt_float4& a, const pt_float4& b) { return P4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+    static float area(const pt_float4& mn, const pt_float4& mx) { float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z; return 2.0f * (dx * dy + dx * dz + dy * dz); }
+
+    void prims() {                                               // computeInfoForBVH, main.cu:20-47
+        size_t n = S.mesh.size();
+        cen.resize(n); lo.resize(n); hi.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const pt_triangle& t = S.mesh[i];
+            const pt_float4 &a = S.points[t.aInd], &b = S.points[t.bInd], &c = S.points[t.cInd];
+            cen[i] = P4((a.x + b.x + c.x) / 3.0f, (a.y + b.y + c.y) / 3.0f, (a.z + b.z + c.z) / 3.0f);
+            lo[i] = P4(fminf(fminf(a.x, b.x), c.x) - 0.000001f, fminf(fminf(a.y, b.y), c.y) - 0.000001f, fminf(fminf(a.z, b.z), c.z) - 0.000001f);
+            hi[i] = P4(fmaxf(fmaxf(a.x, b.x), c.x) + 0.000001f, fmaxf(fmaxf(a.y, b.y), c.y) + 0.000001f, fmaxf(fmaxf(a.z, b.z), c.z) + 0.000001f);
+        }
+    }
+    int count_left(int s, int e, int axis, float split) const { int n = 0; for (int i = s; i < e; i++) n += comp(cen[S.indices[i]], axis) < split; return n; }
+    int partition(int s, int e, int axis, float split) {          // partitionPrimitives, main.cu:49-62
+        int mid = s;
+        for (int i = s; i < e; i++) if (comp(cen[S.indices[i]], axis) < split) { std::swap(S.indices[i], S.indices[mid]); mid++; }
+        return mid;
+    }
+    // SAH, main.cu:64-131: 12 buckets over the node bounds; prefix / suffix sweeps give the same
+    // unions and counts as the reference's nested loops, including bucket i being counted twice on
+    // the right (:102-109).
+    float sah_split(int s, int e, int axis, const pt_float4& mn, const pt_float4& mx) {
+        constexpr int NB = 12;
+        pt_float4 bmin[NB], bmax[NB]; int cnt[NB];
+        for (int i = 0; i < NB; i++) { bmin[i] = P4(FLT_MAX, FLT_MAX, FLT_MAX); bmax[i] = P4(-FLT_MAX, -FLT_MAX, -FLT_MAX); cnt[i] = 0; }
+        const float a0 = comp(mn, axis), ext = comp(mx, axis) - comp(mn, axis);
+        for (int i = s; i < e; i++) {
+            int id = S.indices[i];
+            float q = NB * (comp(cen[id], axis) - a0) / ext;
+            int b = (q == q && fabsf(q) < 1e9f) ? (int)q : 0;
+            b = std::min(std::max(b, 0), NB - 1);
+            cnt[b]++; bmin[b] = vmin(bmin[b], lo[id]); bmax[b] = vmax(bmax[b], hi[id]);
+        }
+        pt_float4 lmin[NB], lmax[NB], rmin[NB], rmax[NB]; int lc[NB], rc[NB];
+        lmin[1] = bmin[0]; lmax[1] = bmax[0]; lc[1] = cnt[0];
+        for (int i = 2; i < NB; i++) { lmin[i] = vmin(lmin[i - 1], bmin[i - 1]); lmax[i] = vmax(lmax[i - 1], bmax[i - 1]); lc[i] = lc[i - 1] + cnt[i - 1]; }
+        rmin[NB - 1] = bmin[NB - 1]; rmax[NB - 1] = bmax[NB - 1]; int suffix = cnt[NB - 1]; rc[NB - 1] = cnt[NB - 1] + suffix;
+        for (int i = NB - 2; i >= 1; i--) { rmin[i] = vmin(bmin[i], rmin[i + 1]); rmax[i] = vmax(bmax[i], rmax[i + 1]); suffix += cnt[i]; rc[i] = cnt[i] + suffix; }
+        float best = FLT_MAX; int bestI = -1;
+        const float whole = area(mn, mx);
+        for (int i = 1; i < NB; i++) {
+            float cost = 1.0f + (lc[i] * area(lmin[i], lmax[i]) + rc[i] * area(rmin[i], rmax[i])) / whole;
+            if (cost < best && (lc[i] > 0 && rc[i] > 0)) { best = cost; bestI = i; }
+        }
+        if (bestI < 0) {                                          // median fallback, main.cu:119-128 (SURVEY App. D ordering)
+            int mid = (s + e) / 2;
+            std::sort(S.indices.begin() + s, S.indices.begin() + e, [&](int a, int b) {
+                float ca = comp(cen[a], axis), cb = comp(cen[b], axis);
+                return ca < cb || (!(cb < ca) && a < b);
+            });
+            return comp(cen[S.indices[mid]], axis);
+        }
+        return a0 + ext * (float(bestI) / float(NB));
+    }
+
+    void build() {
+        struct Job { int s, e, parent; bool left; };
+        std::vector<Job> jobs{{0, (int)S.mesh.size(), -1, false}};
+        while (!jobs.empty()) {
+            Job j = jobs.back(); jobs.pop_back();
+            int id = (int)S.bvh.size();
+            S.bvh.emplace_back();
+            if (j.parent >= 0) (j.left ? S.bvh[j.parent].left : S.bvh[j.parent].right) = id;
+            pt_float4 mn = lo[S.indices[j.s]], mx = hi[S.indices[j.s]];
+            for (int i = j.s; i < j.e; i++) { mn = vmin(mn, lo[S.indices[i]]); mx = vmax(mx, hi[S.indices[i]]); }
+            pt_bvh_node& nd = S.bvh[id];
+            nd.aabbMIN = mn; nd.aabbMAX = mx;
+            const int n = j.e - j.s;
+            auto leaf = [&]() { nd.first = j.s; nd.primCount = n; nd.left = nd.right = -1; S.largestLeaf = std::max(S.largestLeaf, n); };
+            if (n <= leafMax) { leaf(); continue; }
+            float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+            int axis = (dy > dx && dy > dz) ? 1 : ((dz > dx && dz > dy) ? 2 : 0);
+            float split = sah_split(j.s, j.e, axis, mn, mx);
+            int nl = count_left(j.s, j.e, axis, split);
+            int mid = j.s;
+            if (nl > 0 && nl < n - 1) mid = partition(j.s, j.e, axis, split);
+            else {                                                // centroid-mean retry, main.cu:192-202
+                S.backups++;
+                float sum = 0.0f;
+                for (int i = j.s; i < j.e; i++) sum += comp(cen[S.indices[i]], axis);
+                split = sum / n;
+            }
+            nl = count_left(j.s, j.e, axis, split);
+            if (nl > 0 && nl < n - 1) mid = partition(j.s, j.e, axis, split);
+            else { leaf(); continue; }                            // forced (possibly oversize) leaf, main.cu:213-221
+            nd.primCount = 0; nd.first = -1; nd.left = nd.right = -1;
+            jobs.push_back({mid, j.e, id, false});                // right is built after the whole left subtree
+            jobs.push_back({j.s, mid, id, true});
+        }
+    }
+};
+
+int tree_depth(const std::vector<pt_bvh_node>& n) {
+    int best = 0;
+    std::vector<std::pair<int, int>> st{{0, 1}};
+    while (!st.empty()) {
+        auto [i, d] = st.back(); st.pop_back();
+        best = std::max(best, d);
+        if (n[i].primCount > 0) continue;
+        st.push_back({n[i].left, d + 1}); st.push_back({n[i].right, d + 1});
+    }
+    return best;
+}
+
+// ---- camera (objects.cuh:221-264, 309-325; host libm like the reference) ------------------------
+F3 rotX(F3 v, float a) { float c = cosf(a), s = sinf(a); return F3{v.x, v.y * c - v.z * s, v.y * s + v.z * c}; }
+F3 rotY(F3 v, float a) { float c = cosf(a), s = sinf(a); return F3{v.x * c + v.z * s, v.y, -v.x * s + v.z * c}; }
+F3 rotZ(F3 v, float a) { float c = cosf(a), s = sinf(a); return F3{v.x * c - v.y * s, v.x * s + v.y * c, v.z}; }
+pt_float4 unit(F3 v) { float il = 1.0f / sqrtf(dot3(v, v)); return P4(v.x * il, v.y * il, v.z * il); }
+
+void make_camera(bool pinhole, const float pos[3], const float rot[3], float fov, float aperture, float focal, int w, int h, pt_camera& c) {
+    std::memset(&c, 0, sizeof(c));
+    c.cameraOrigin = P4(pos[0], pos[1], pos[2]);
+    c.w = w; c.h = h;
+    c.fovScale = tanf((fov * 0.5f) * (3.141592f / 180.0f));
+    c.xRot = rot[0] * (3.14159265f / 180.0f); c.yRot = rot[1] * (3.14159265f / 180.0f); c.zRot = rot[2] * (3.14159265f / 180.0f);
+    c.aperture = pinhole ? 0.000001f : aperture;      // objects.cuh:234
+    c.focalDist = pinhole ? 1.0f / fov : focal;       // objects.cuh:235
+    c.antiAliasJitterDist = 2.0f;
+    c.forward = unit(rotZ(rotY(rotX(F3{0, 0, -1}, c.xRot), c.yRot), c.zRot));
+    c.right = unit(rotZ(rotY(rotX(F3{1, 0, 0}, c.xRot), c.yRot), c.zRot));
+    c.up = unit(rotZ(rotY(rotX(F3{0, 1, 0}, c.xRot), c.yRot), c.zRot));
+}
+
+// ---- image output (imageUtil.cu:69-100, 202-232) --------------------------------------------------
+float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+float aces(float c) { return clamp01((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f)); }
+
+}  // namespace
+
+extern "C" {
+
+novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number) {
+    if (!config_path) return nullptr;
+    novum_scene* S = new novum_scene();
+    if (!parse_config(config_path, S->cfg)) { delete S; return nullptr; }
+    std::string base;
+    if (base_dir) base = base_dir;
+    else { std::string p = config_path; size_t k = p.find_last_of('/'); base = (k == std::string::npos) ? "." : p.substr(0, k); }
+    const Config& c = S->cfg;
+    make_camera(c.pinhole, c.camPos, c.camRot, c.fov, c.aperture, c.focalDist, c.width, c.height, S->cam);
+    // The four texture BMPs of main.cu:371-374 are absent offline: loadBMPToImage returns 0x0
+    // images (imageUtil.cu:146-149), i.e. every start index and size is 0.
+    const int zeros[4] = {0, 0, 0, 0};
+    material_table(*S, zeros, zeros, zeros);
+    for (const MeshLine& m : c.meshes) {
+        std::string p = (!m.path.empty() && m.path[0] == '/') ? m.path : base + "/" + m.path;
+        float e[3] = {m.mult * m.rgb[0], m.mult * m.rgb[1], m.mult * m.rgb[2]};
+        bool emissive = dot3(F3{m.rgb[0], m.rgb[1], m.rgb[2]}, F3{m.rgb[0], m.rgb[1], m.rgb[2]}) > 0.0f;
+        float off[3] = {0.0f, emissive ? -0.01f * render_number : 0.0f, 0.0f};        // main.cu:476-478
+        read_obj(p, *S, e, m.material, off);
+    }
+    if (S->mesh.empty()) { fprintf(stderr, "Error: No triangles loaded.\n"); delete S; return nullptr; }
+    S->indices.resize(S->mesh.size());
+    for (size_t i = 0; i < S->mesh.size(); i++) S->indices[i] = (int32_t)i;
+    Builder b{*S, {}, {}, {}, c.leafSize};
+    b.prims();
+    b.build();
+    S->treeDepth = tree_depth(S->bvh);
+    return S;
+}
+
+void novum_scene_free(novum_scene* s) { delete s; }
+
+void novum_scene_info(const novum_scene* s, int32_t* info) {
+    int v[16] = {s->cfg.width, s->cfg.height, s->cfg.spp, s->cfg.maxDepth, integrator_id(s->cfg.integrator), s->cfg.leafSize,
+                 (int)s->mesh.size(), (int)s->lights.size(), (int)s->bvh.size(), (int)s->points.size(), (int)s->normals.size(),
+                 (int)s->uvs.size(), (int)s->mats.size(), s->largestLeaf, s->backups, s->treeDepth};
+    std::memcpy(info, v, sizeof(v));
+}
+
+void novum_scene_desc(const novum_scene* s, pt_scene_desc* d) {
+    d->positions = s->points.data(); d->n_positions = (int)s->points.size();
+    d->normals = s->normals.data(); d->n_normals = (int)s->normals.size();
+    d->uvs = s->uvs.data(); d->n_uvs = (int)s->uvs.size();
+    d->triangles = s->mesh.data(); d->n_triangles = (int)s->mesh.size();
+    d->lights = s->lights.data(); d->n_lights = (int)s->lights.size();
+    d->bvh = s->bvh.data(); d->n_nodes = (int)s->bvh.size();
+    d->bvh_indices = s->indices.data();
+    d->materials = s->mats.data(); d->n_materials = (int)s->mats.size();
+    d->textures = s->textures.data(); d->n_texels = (int)s->textures.size();
+}
+
+void novum_scene_camera(const novum_scene* s, pt_camera* out) { *out = s->cam; }
+
+void novum_make_camera(int pinhole, const float* pos, const float* rot, float fov, float aperture, float focal, int w, int h, pt_camera* out) {
+    make_camera(pinhole != 0, pos, rot, fov, aperture, focal, w, h, *out);
+}
+
+void novum_finalise(float* rgba, int n, int spp) {                 // main.cu:860-870
+    const float s = (float)spp;
+    for (int i = 0; i < n; i++) {
+        float* p = rgba + 4 * (size_t)i;
+        p[0] /= s; p[1] /= s; p[2] /= s;
+        if (std::isnan(p[0]) || std::isnan(p[1]) || std::isnan(p[2])) { p[0] = 1.0f; p[1] = 0.0f; p[2] = 1.0f; p[3] = 0.0f; }
+        if (std::isinf(p[0]) || std::isinf(p[1]) || std::isinf(p[2])) { p[0] = 0.0f; p[1] = 1.0f; p[2] = 0.0f; p[3] = 0.0f; }
+    }
+}
+
+int novum_save_bmp(const char* path, const float* rgba, int w, int h, int post) {      // imageUtil.cu:69-100, 234-257
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    const int row = (3 * w + 3) & ~3;
+    const uint32_t img = (uint32_t)row * h, off = 54, size = off + img;
+    unsigned char hd[54] = {0};
+    hd[0] = 'B'; hd[1] = 'M';
+    std::memcpy(hd + 2, &size, 4); std::memcpy(hd + 10, &off, 4);
+    uint32_t ih = 40; std::memcpy(hd + 14, &ih, 4);
+    int32_t ww = w, hh = h; std::memcpy(hd + 18, &ww, 4); std::memcpy(hd + 22, &hh, 4);
+    uint16_t planes = 1, bpp = 24; std::memcpy(hd + 26, &planes, 2); std::memcpy(hd + 28, &bpp, 2);
+    std::memcpy(hd + 34, &img, 4);
+    fwrite(hd, 1, 54, f);
+    std::vector<unsigned char> line(row, 0);
+    const float ig = 1.0f / 2.2f;
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const float* p = rgba + 4 * ((size_t)y * w + x);
+            float r = p[0], g = p[1], b = p[2];
+            if (post) { r = powf(aces(r), ig); g = powf(aces(g), ig); b = powf(aces(b), ig); }      // toneMap + gammaCorrect
+            line[x * 3 + 0] = (unsigned char)(clamp01(b) * 255.0f + 0.5f);
+            line[x * 3 + 1] = (unsigned char)(clamp01(g) * 255.0f + 0.5f);
+            line[x * 3 + 2] = (unsigned char)(clamp01(r) * 255.0f + 0.5f);
+        }
+        fwrite(line.data(), 1, row, f);
+    }
+    fclose(f);
+    return 0;
+}
+
+// hipMalloc / hipMemset / hipMemcpy / hipFree without pulling the HIP headers into this file
+int pt_host_alloc_zero_(void** p, size_t bytes);
+int pt_host_download_free_(void* d, void* h, size_t bytes);
+
+int novum_init_render(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path) {
+    novum_scene* S = novum_scene_load(config_path, base_dir, render_number);
+    if (!S) return -1;
+    int integ = integrator_id(S->cfg.integrator);
+    if (integ != PT_UNIDIRECTIONAL && integ != PT_NAIVE_UNIDIRECTIONAL) {
+        fprintf(stderr, "novum_init_render: integrator '%s' is outside the accelerated path\n", S->cfg.integrator.c_str());
+        novum_scene_free(S);
+        return -3;
+    }
+    pt_scene_desc d;
+    novum_scene_desc(S, &d);
+    pt_scene* dev = pt_scene_create(&d);
+    if (!dev) { fprintf(stderr, "novum_init_render: %s\n", pt_last_error()); novum_scene_free(S); return -2; }
+    const int w = S->cfg.width, h = S->cfg.height;
+    const size_t bytes = (size_t)w * h * 16;
+    void* colors = nullptr;                                            // out_colors, main.cu:337-339
+    int rc = pt_host_alloc_zero_(&colors, bytes);
+    std::vector<float> host((size_t)w * h * 4);
+    if (rc == 0) {
+        rc = (integ == PT_UNIDIRECTIONAL) ? pt_launch_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors)     // main.cu:565
+                                          : pt_launch_naive_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors);   // main.cu:677
+        int rc2 = pt_host_download_free_(colors, host.data(), bytes);  // main.cu:854-855, 889
+        if (rc == 0) rc = rc2;
+    }
+    if (rc == 0) {
+        novum_finalise(host.data(), w * h, S->cfg.spp);
+        if (out_rgba) std::memcpy(out_rgba, host.data(), bytes);
+        if (bmp_path) rc = novum_save_bmp(bmp_path, host.data(), w, h, S->cfg.postProcess ? 1 : 0);
+    } else fprintf(stderr, "novum_init_render: %s\n", pt_last_error());
+    pt_scene_destroy(dev);
+    novum_scene_free(S);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,563 @@
+// pt_api.hip — implementation of the C ABI in include/pt_api.h: scene re-pack + upload, the
+// launcher boundary (launch_unidirectional / launch_naive_unidirectional, deviceCode.cuh:8-12)
+// and the probe entry points. Host code only; the kernels live in pt_kernels.hip.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_params.h"
+#include "xorwow_host.h"
+
+using namespace pt;
+
+static_assert(sizeof(pt_bvh_node) == 48 && sizeof(pt_triangle) == 80 && sizeof(pt_material) == 176 && sizeof(pt_camera) == 112,
+              "boundary structs must keep the reference's CUDA layouts (SURVEY.md Appendix A)");
+static_assert(offsetof(pt_triangle, emission) == 48 && offsetof(pt_triangle, lightInd) == 64, "Triangle layout");
+static_assert(offsetof(pt_material, type) == 32 && offsetof(pt_material, albedo) == 48 && offsetof(pt_material, eta) == 80 &&
+              offsetof(pt_material, ior) == 112 && offsetof(pt_material, isSpecular) == 128 && offsetof(pt_material, absorption) == 144 &&
+              offsetof(pt_material, priority) == 160, "Material layout");
+static_assert(offsetof(pt_camera, forward) == 64 && offsetof(pt_camera, fovScale) == 44, "Camera layout");
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail(-2, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        bytes = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct pt_scene {
+    int device = 0;
+    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
+    DevBuf rng, spill, tilebuf, colors, pixcnt;       // work buffers, grown on demand
+    DeviceScene ds{};
+    int stackNeed = 0, nInternal = 0;
+    float lastKernelMs = 0.0f;
+    bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int pt_api_version(void) { return PT_API_VERSION; }
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+int pt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(-2, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+void pt_scene_destroy(pt_scene* s) {
+    if (!s) return;
+    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals,
+                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt};
+    for (DevBuf* b : all) b->release();
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes) {
+    if (int r = b.ensure(std::max<size_t>(bytes, 16))) return r;
+    if (bytes) HIP_OK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Re-pack the reference's data model for gfx950.
+static int repack(pt_scene* s, const pt_scene_desc* d) {
+    const int nT = d->n_triangles, nN = d->n_nodes;
+    if (nT <= 0 || nN <= 0 || !d->triangles || !d->bvh || !d->bvh_indices || !d->positions || !d->materials)
+        return fail(-1, "pt_scene_create: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
+    if (d->n_materials <= 0 || d->n_materials > 256) return fail(-1, "pt_scene_create: %d materials (1..256 supported)", d->n_materials);
+
+    // --- internal nodes in the reference's (pre-order) numbering, compacted ---
+    std::vector<int> internalId(nN, -1);
+    int nInternal = 0;
+    for (int i = 0; i < nN; i++) {
+        const pt_bvh_node& n = d->bvh[i];
+        if (n.primCount > 0) {
+            if (n.first < 0 || n.first + n.primCount > nT) return fail(-1, "pt_scene_create: leaf %d range [%d,+%d) out of bounds", i, n.first, n.primCount);
+        } else {
+            if (n.left < 0 || n.right < 0 || n.left >= nN || n.right >= nN) return fail(-1, "pt_scene_create: internal node %d has child out of range", i);
+            internalId[i] = nInternal++;
+        }
+    }
+    auto childRef = [&](int c) -> int32_t { return d->bvh[c].primCount > 0 ? ~d->bvh[c].first : internalId[c]; };
+    std::vector<PNode> nodes(std::max(nInternal, 1));
+    std::vector<uint8_t> leafEnd(nT, 0);
+    for (int i = 0; i < nN; i++) {
+        const pt_bvh_node& n = d->bvh[i];
+        if (n.primCount > 0) { leafEnd[n.first + n.primCount - 1] = 1; continue; }
+        PNode& p = nodes[internalId[i]];
+        const pt_bvh_node& L = d->bvh[n.left];
+        const pt_bvh_node& R = d->bvh[n.right];
+        p.lmin[0] = L.aabbMIN.x; p.lmin[1] = L.aabbMIN.y; p.lmin[2] = L.aabbMIN.z;
+        p.lmax[0] = L.aabbMAX.x; p.lmax[1] = L.aabbMAX.y; p.lmax[2] = L.aabbMAX.z;
+        p.rmin[0] = R.aabbMIN.x; p.rmin[1] = R.aabbMIN.y; p.rmin[2] = R.aabbMIN.z;
+        p.rmax[0] = R.aabbMAX.x; p.rmax[1] = R.aabbMAX.y; p.rmax[2] = R.aabbMAX.z;
+        p.left = childRef(n.left); p.right = childRef(n.right); p.pad0 = p.pad1 = 0;
+    }
+    // stack need = the largest number of internal nodes on a root-to-leaf path (each can leave one
+    // far child pending); also rejects cycles.
+    int stackNeed = 0;
+    {
+        std::vector<std::pair<int, int>> st; st.push_back({0, 1});
+        size_t visited = 0;
+        while (!st.empty()) {
+            auto [i, depth] = st.back(); st.pop_back();
+            if (++visited > (size_t)nN) return fail(-1, "pt_scene_create: BVH is not a tree");
+            if (d->bvh[i].primCount > 0) continue;
+            stackNeed = std::max(stackNeed, depth);
+            st.push_back({d->bvh[i].left, depth + 1});
+            st.push_back({d->bvh[i].right, depth + 1});
+        }
+    }
+    if (stackNeed > 128) return fail(-1, "pt_scene_create: BVH depth %d exceeds the reference's nodeStack[128] (integratorUtilities.cuh:89)", stackNeed);
+
+    // --- triangles in leaf order ---
+    auto pos = [&](int i, const char* what, int tri, bool& ok) -> pt_float4 {
+        if (i < 0 || i >= d->n_positions) { ok = false; fail(-1, "pt_scene_create: triangle %d %s index %d out of range", tri, what, i); return pt_float4{0, 0, 0, 0}; }
+        return d->positions[i];
+    };
+    std::vector<PTri> tris(nT);
+    for (int i = 0; i < nT; i++) {
+        int idx = d->bvh_indices[i];
+        if (idx < 0 || idx >= nT) return fail(-1, "pt_scene_create: BVHindices[%d] = %d out of range", i, idx);
+        const pt_triangle& t = d->triangles[idx];
+        bool ok = true;
+        pt_float4 a = pos(t.aInd, "a", idx, ok), b = pos(t.bInd, "b", idx, ok), c = pos(t.cInd, "c", idx, ok);
+        if (!ok) return -1;
+        if (t.materialID < 0 || t.materialID >= d->n_materials) return fail(-1, "pt_scene_create: triangle %d material %d out of range", idx, t.materialID);
+        PTri& p = tris[i];
+        p.v0[0] = a.x; p.v0[1] = a.y; p.v0[2] = a.z;
+        p.e1[0] = b.x - a.x; p.e1[1] = b.y - a.y; p.e1[2] = b.z - a.z;      // trib - tria, integratorUtilities.cuh:13
+        p.e2[0] = c.x - a.x; p.e2[1] = c.y - a.y; p.e2[2] = c.z - a.z;      // tric - tria, :14
+        p.idx = (uint32_t)idx | (leafEnd[i] ? 0x80000000u : 0u);
+        p.material = t.materialID;
+        p.flags = d->materials[t.materialID].type == PT_MAT_LEAF ? 1u : 0u;
+    }
+    // --- hit attributes by original index ---
+    std::vector<PAttr> attrs(nT);
+    for (int i = 0; i < nT; i++) {
+        const pt_triangle& t = d->triangles[i];
+        PAttr& a = attrs[i];
+        const int ni[3] = {t.naInd, t.nbInd, t.ncInd}, ui[3] = {t.uvaInd, t.uvbInd, t.uvcInd};
+        float* nd[3] = {a.n0, a.n1, a.n2}; float* ud[3] = {a.uv0, a.uv1, a.uv2};
+        for (int k = 0; k < 3; k++) {
+            if (ni[k] < 0 || ni[k] >= d->n_normals || !d->normals) return fail(-1, "pt_scene_create: triangle %d normal index %d out of range (faces without vn must be given a normal by the loader)", i, ni[k]);
+            if (ui[k] < 0 || ui[k] >= d->n_uvs || !d->uvs) return fail(-1, "pt_scene_create: triangle %d uv index %d out of range", i, ui[k]);
+            nd[k][0] = d->normals[ni[k]].x; nd[k][1] = d->normals[ni[k]].y; nd[k][2] = d->normals[ni[k]].z;
+            ud[k][0] = d->uvs[ui[k]].x; ud[k][1] = d->uvs[ui[k]].y;
+        }
+        a.emission[0] = t.emission.x; a.emission[1] = t.emission.y; a.emission[2] = t.emission.z;
+        a.material = t.materialID;
+        a.lightInd = (t.lightInd >= 0 && t.lightInd < d->n_lights) ? t.lightInd : -51;
+    }
+    // --- lights ---
+    std::vector<PLight> lights(std::max(d->n_lights, 1));
+    std::memset(lights.data(), 0, lights.size() * sizeof(PLight));
+    for (int i = 0; i < d->n_lights; i++) {
+        const pt_triangle& t = d->lights[i];
+        bool ok = true;
+        pt_float4 a = pos(t.aInd, "a", i, ok), b = pos(t.bInd, "b", i, ok), c = pos(t.cInd, "c", i, ok);
+        if (!ok) return -1;
+        if (t.naInd < 0 || t.naInd >= d->n_normals) return fail(-1, "pt_scene_create: light %d normal index out of range", i);
+        PLight& L = lights[i];
+        L.a[0] = a.x; L.a[1] = a.y; L.a[2] = a.z; L.b[0] = b.x; L.b[1] = b.y; L.b[2] = b.z; L.c[0] = c.x; L.c[1] = c.y; L.c[2] = c.z;
+        L.na[0] = d->normals[t.naInd].x; L.na[1] = d->normals[t.naInd].y; L.na[2] = d->normals[t.naInd].z;
+        L.emission[0] = t.emission.x; L.emission[1] = t.emission.y; L.emission[2] = t.emission.z;
+    }
+    // --- materials ---
+    std::vector<PMat> mats(d->n_materials);
+    std::memset(mats.data(), 0, mats.size() * sizeof(PMat));
+    for (int i = 0; i < d->n_materials; i++) {
+        const pt_material& m = d->materials[i];
+        PMat& p = mats[i];
+        p.type = m.type;
+        p.flags = (m.hasTexture ? kMatHasTexture : 0) | (m.hasTransMap ? kMatHasTransMap : 0) | (m.isSpecular ? kMatSpecular : 0) | (m.boundary ? kMatBoundary : 0);
+        p.priority = m.priority;
+        p.texStart = m.startInd; p.texW = m.width; p.texH = m.height;
+        if ((m.hasTexture || m.hasTransMap) && m.width > 0 && m.height > 0 &&
+            (m.startInd < 0 || (long long)m.startInd + (long long)m.width * m.height > d->n_texels))
+            return fail(-1, "pt_scene_create: material %d texture window exceeds the texel array", i);
+        p.roughness = m.roughness; p.ior = m.ior; p.transmission = m.transmission;
+        p.albedo[0] = m.albedo.x; p.albedo[1] = m.albedo.y; p.albedo[2] = m.albedo.z;
+        p.eta[0] = m.eta.x; p.eta[1] = m.eta.y; p.eta[2] = m.eta.z;
+        p.k[0] = m.k.x; p.k[1] = m.k.y; p.k[2] = m.k.z;
+        p.absorption[0] = m.absorption.x; p.absorption[1] = m.absorption.y; p.absorption[2] = m.absorption.z;
+    }
+
+    if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
+    if (int r = upload(s->tris, tris.data(), tris.size() * sizeof(PTri))) return r;
+    if (int r = upload(s->attrs, attrs.data(), attrs.size() * sizeof(PAttr))) return r;
+    if (int r = upload(s->lights, lights.data(), lights.size() * sizeof(PLight))) return r;
+    if (int r = upload(s->mats, mats.data(), mats.size() * sizeof(PMat))) return r;
+    if (int r = upload(s->textures, d->textures, (size_t)std::max(d->n_texels, 0) * sizeof(float4))) return r;
+    const std::vector<uint32_t>& jt = xorwow_host::jump_table();
+    if (int r = upload(s->jump, jt.data(), jt.size() * sizeof(uint32_t))) return r;
+    if (int r = s->totals.ensure(8 * sizeof(unsigned long long))) return r;
+    HIP_OK(hipMemset(s->totals.p, 0, 8 * sizeof(unsigned long long)));
+
+    s->nInternal = nInternal;
+    s->stackNeed = stackNeed;
+    s->ds.nodes = (const PNode*)s->nodes.p; s->ds.tris = (const PTri*)s->tris.p; s->ds.attrs = (const PAttr*)s->attrs.p;
+    s->ds.lights = (const PLight*)s->lights.p; s->ds.mats = (const PMat*)s->mats.p; s->ds.textures = (const float4*)s->textures.p;
+    s->ds.rootRef = childRef(0);
+    s->ds.nLights = d->n_lights; s->ds.nTris = nT;
+    s->ds.stackSpill = std::max(0, stackNeed - kStackLds);
+    return 0;
+}
+
+pt_scene* pt_scene_create(const pt_scene_desc* desc) {
+    if (!desc) { fail(-1, "pt_scene_create: null desc"); return nullptr; }
+    pt_scene* s = new pt_scene();
+    if (hipGetDevice(&s->device) != hipSuccess) { fail(-2, "pt_scene_create: no HIP device (the path has no CPU fallback)"); delete s; return nullptr; }
+    if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { fail(-2, "hipEventCreate failed"); pt_scene_destroy(s); return nullptr; }
+    return s;
+}
+
+// ---- helpers ----------------------------------------------------------------------------------
+static int resolve_tiles(int w, int h, const pt_tile_range* tiles, TileSpan& t) {
+    if (w <= 0 || h <= 0) return fail(-1, "bad image size %dx%d", w, h);
+    t.tilesX = (w + 7) / 8;
+    int total = t.tilesX * ((h + 7) / 8);
+    if (!tiles) { t.first = 0; t.stride = 1; t.count = total; return 0; }
+    t.first = tiles->first; t.stride = tiles->stride; t.count = tiles->count;
+    if (t.count < 0 || t.stride < 1 || t.first < 0) return fail(-1, "bad tile range {first %d, stride %d, count %d}", t.first, t.stride, t.count);
+    if (t.count > 0 && (long long)t.first + (long long)(t.count - 1) * t.stride >= total)
+        return fail(-1, "tile range {first %d, stride %d, count %d} exceeds the %d tiles of a %dx%d image", t.first, t.stride, t.count, total, w, h);
+    return 0;
+}
+
+static CamK cam_to_kernel(const pt_camera& c) {
+    CamK k;
+    k.origin = V3{c.cameraOrigin.x, c.cameraOrigin.y, c.cameraOrigin.z};
+    k.forward = V3{c.forward.x, c.forward.y, c.forward.z};
+    k.right = V3{c.right.x, c.right.y, c.right.z};
+    k.up = V3{c.up.x, c.up.y, c.up.z};
+    k.w = c.w; k.h = c.h; k.aperture = c.aperture; k.focalDist = c.focalDist; k.fovScale = c.fovScale; k.jitter = c.antiAliasJitterDist;
+    return k;
+}
+
+static int check_render_args(pt_scene* s, const pt_camera* cam, int spp, int integrator) {
+    if (!s || !cam) return fail(-1, "null scene or camera");
+    if (spp < 0) return fail(-1, "negative sample count");
+    if (integrator != PT_UNIDIRECTIONAL && integrator != PT_NAIVE_UNIDIRECTIONAL)
+        return fail(-3, "integrator %d is out of scope: only UNIDIRECTIONAL (0) and NAIVE_UNIDIRECTIONAL (2) are on this path", integrator);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != s->device) return fail(-1, "scene lives on HIP device %d but the current device is %d", s->device, dev);
+    return 0;
+}
+
+// rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
+static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
+                        uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool timeIt) {
+    if (t.count == 0) return 0;
+    // the reference keys the stream by the camera's image size (y*w+x with the launch's w, deviceCode.cu:59)
+    if (int r = s->rng.ensure((size_t)t.count * 384 * sizeof(uint32_t))) return r;
+    int blocks = megakernel_blocks(t.count);
+    if (s->ds.stackSpill > 0)
+        if (int r = s->spill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
+    HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
+    KParams P;
+    P.S = s->ds;
+    P.cam = cam_to_kernel(*cam);
+    P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
+    P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
+    P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
+    P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
+    P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;
+    (void)timeIt;
+    HIP_OK(hipEventRecord(s->ev0, stream));            // HIP events on the launch stream, around the megakernel only
+    HIP_OK(launch_megakernel(integrator, count, P, stream));
+    HIP_OK(hipEventRecord(s->ev1, stream));
+    s->evPending = true;
+    return 0;
+}
+
+int pt_render_tiles_device(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
+                           uint64_t seed, const pt_tile_range* tiles, void* d_tile_rgba, int count_work, void* stream) {
+    if (int r = check_render_args(s, cam, spp, integrator)) return r;
+    if (!d_tile_rgba) return fail(-1, "null tile buffer");
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, tiles, t)) return r;
+    return render_tiles(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, t, d_tile_rgba, nullptr, count_work != 0, (hipStream_t)stream, false);
+}
+
+int pt_untile_device(int w, int h, const pt_tile_range* tiles, const void* d_tile_rgba, void* d_colors, void* stream) {
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, tiles, t)) return r;
+    HIP_OK(launch_untile(w, h, t, (const float4*)d_tile_rgba, (float4*)d_colors, (hipStream_t)stream));
+    return 0;
+}
+int pt_tile_device(int w, int h, const pt_tile_range* tiles, const void* d_colors, void* d_tile_rgba, void* stream) {
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, tiles, t)) return r;
+    HIP_OK(launch_tile(w, h, t, (const float4*)d_colors, (float4*)d_tile_rgba, (hipStream_t)stream));
+    return 0;
+}
+
+// scan-line DEVICE accumulator in / out, blocking; the body of both reference launchers.
+static int launch_on_colors(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
+                            uint64_t seed, const pt_tile_range* tiles, void* d_colors, uint32_t* d_pixcnt, bool count) {
+    if (int r = check_render_args(s, cam, spp, integrator)) return r;
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, tiles, t)) return r;
+    if (int r = s->tilebuf.ensure(std::max<size_t>((size_t)t.count * 64 * sizeof(float4), 16))) return r;
+    HIP_OK(launch_tile(w, h, t, (const float4*)d_colors, (float4*)s->tilebuf.p, nullptr));
+    if (int r = render_tiles(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, t, s->tilebuf.p, d_pixcnt, count, nullptr, true)) return r;
+    HIP_OK(launch_untile(w, h, t, (const float4*)s->tilebuf.p, (float4*)d_colors, nullptr));
+    HIP_OK(hipDeviceSynchronize());                 // cudaDeviceSynchronize, deviceCode.cu:608
+    return 0;
+}
+
+int pt_launch_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors) {
+    return launch_on_colors(scene, &camera, w, h, numSample, maxDepth, PT_UNIDIRECTIONAL, useMIS, 103033ull, nullptr, d_colors, nullptr, false);
+}
+int pt_launch_naive_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors) {
+    return launch_on_colors(scene, &camera, w, h, numSample, maxDepth, PT_NAIVE_UNIDIRECTIONAL, useMIS, 103033ull, nullptr, d_colors, nullptr, false);
+}
+
+int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
+                      const pt_tile_range* tiles, float* out, uint32_t* outCounters) {
+    if (!out) return fail(-1, "null output buffer");
+    if (int r = check_render_args(s, cam, spp, integrator)) return r;
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, tiles, t)) return r;
+    size_t px = (size_t)w * h;
+    if (int r = s->colors.ensure(px * sizeof(float4))) return r;
+    HIP_OK(hipMemcpy(s->colors.p, out, px * sizeof(float4), hipMemcpyHostToDevice));
+    uint32_t* dpc = nullptr;
+    if (outCounters) {
+        if (int r = s->pixcnt.ensure(std::max<size_t>((size_t)t.count * 512 * sizeof(uint32_t), 16))) return r;
+        dpc = (uint32_t*)s->pixcnt.p;
+    }
+    if (int r = launch_on_colors(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, s->colors.p, dpc, true)) return r;
+    HIP_OK(hipMemcpy(out, s->colors.p, px * sizeof(float4), hipMemcpyDeviceToHost));
+    if (outCounters) {
+        std::vector<uint32_t> tmp((size_t)t.count * 512);
+        HIP_OK(hipMemcpy(tmp.data(), dpc, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int lt = 0; lt < t.count; lt++) {
+            int tile = t.first + lt * t.stride;
+            for (int lane = 0; lane < 64; lane++) {
+                int x = (tile % t.tilesX) * 8 + (lane & 7), y = (tile / t.tilesX) * 8 + (lane >> 3);
+                if (x >= w || y >= h) continue;
+                for (int k = 0; k < 8; k++) outCounters[((size_t)y * w + x) * 8 + k] = tmp[(size_t)lt * 512 + k * 64 + lane];
+            }
+        }
+    }
+    return 0;
+}
+
+int pt_render(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
+              const pt_tile_range* tiles, float* out) {
+    return pt_render_counted(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, nullptr);
+}
+
+int pt_get_counters(pt_scene* s, pt_counters* out) {
+    if (!s || !out) return fail(-1, "null argument");
+    HIP_OK(hipMemcpy(out, s->totals.p, sizeof(pt_counters), hipMemcpyDeviceToHost));
+    return 0;
+}
+int pt_reset_counters(pt_scene* s) {
+    if (!s) return fail(-1, "null scene");
+    HIP_OK(hipMemset(s->totals.p, 0, sizeof(pt_counters)));
+    return 0;
+}
+float pt_last_kernel_ms(pt_scene* s) {
+    if (!s) return -1.0f;
+    if (s->evPending) {                                // waits for the last megakernel launch to finish
+        if (hipEventSynchronize(s->ev1) != hipSuccess || hipEventElapsedTime(&s->lastKernelMs, s->ev0, s->ev1) != hipSuccess) return -1.0f;
+        s->evPending = false;
+    }
+    return s->lastKernelMs;
+}
+
+// device-memory helpers for novum_host.cpp (which stays free of HIP headers)
+int pt_host_alloc_zero_(void** p, size_t bytes) {
+    HIP_OK(hipMalloc(p, std::max<size_t>(bytes, 16)));
+    HIP_OK(hipMemset(*p, 0, bytes));
+    return 0;
+}
+int pt_host_download_free_(void* d, void* h, size_t bytes) {
+    hipError_t e = hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(-2, "hipMemcpy D2H failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ---- probes -------------------------------------------------------------------------------------
+struct Scratch {      // RAII device scratch for the probe entry points
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    void* get(size_t bytes, const void* init = nullptr) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (init && bytes) { if (hipMemcpy(p, init, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr; }
+        return p;
+    }
+};
+#define SCRATCH(var, type, bytes, init)                              \
+    type* var = (type*)sc.get(bytes, init);                          \
+    if (!var) return fail(-2, "probe: device scratch allocation failed")
+
+static int jump_device(Scratch& sc, const uint32_t*& dj) {
+    const std::vector<uint32_t>& jt = xorwow_host::jump_table();
+    dj = (const uint32_t*)sc.get(jt.size() * 4, jt.data());
+    return dj ? 0 : fail(-2, "probe: device scratch allocation failed");
+}
+
+int pt_probe_rng(uint64_t seed, int n, const uint32_t* subseq, int nDraws, uint32_t* outState6, uint32_t* outU32, float* outUni) {
+    if (n <= 0 || nDraws < 0) return fail(-1, "bad sizes");
+    Scratch sc;
+    const uint32_t* dj; if (int r = jump_device(sc, dj)) return r;
+    SCRATCH(dsub, uint32_t, (size_t)n * 4, subseq);
+    SCRATCH(dst, uint32_t, (size_t)n * 24, nullptr);
+    SCRATCH(du, uint32_t, (size_t)n * nDraws * 4, nullptr);
+    SCRATCH(df, float, (size_t)n * nDraws * 4, nullptr);
+    HIP_OK(launch_probe_rng(dj, seed, n, dsub, nDraws, dst, du, df, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    if (outState6) HIP_OK(hipMemcpy(outState6, dst, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (outU32 && nDraws) HIP_OK(hipMemcpy(outU32, du, (size_t)n * nDraws * 4, hipMemcpyDeviceToHost));
+    if (outUni && nDraws) HIP_OK(hipMemcpy(outUni, df, (size_t)n * nDraws * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_math(int n, const float* x, float* oSin, float* oCos, float* oExp, float* oRsqrt, float* oPow5) {
+    if (n <= 0) return fail(-1, "bad sizes");
+    Scratch sc;
+    SCRATCH(dx, float, (size_t)n * 4, x);
+    float* d[5]; float* outs[5] = {oSin, oCos, oExp, oRsqrt, oPow5};
+    for (int k = 0; k < 5; k++) { d[k] = (float*)sc.get((size_t)n * 4); if (!d[k]) return fail(-2, "probe: device scratch allocation failed"); }
+    HIP_OK(launch_probe_math(n, dx, d[0], d[1], d[2], d[3], d[4], nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    for (int k = 0; k < 5; k++) if (outs[k]) HIP_OK(hipMemcpy(outs[k], d[k], (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_camera_rays(const pt_camera* cam, uint64_t seed, int n, const int32_t* xy, float* outRays6) {
+    if (!cam || n <= 0) return fail(-1, "bad arguments");
+    Scratch sc;
+    const uint32_t* dj; if (int r = jump_device(sc, dj)) return r;
+    std::vector<uint32_t> sub(n);
+    for (int i = 0; i < n; i++) sub[i] = (uint32_t)(xy[2 * i + 1] * cam->w + xy[2 * i]);
+    SCRATCH(dsub, uint32_t, (size_t)n * 4, sub.data());
+    SCRATCH(dst, uint32_t, (size_t)n * 24, nullptr);
+    SCRATCH(du, uint32_t, 16, nullptr);
+    SCRATCH(df, float, 16, nullptr);
+    SCRATCH(dxy, int, (size_t)n * 8, xy);
+    SCRATCH(dout, float, (size_t)n * 24, nullptr);
+    HIP_OK(launch_probe_rng(dj, seed, n, dsub, 0, dst, du, df, nullptr));
+    HIP_OK(launch_probe_camera(dst, cam_to_kernel(*cam), n, dxy, dout, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(outRays6, dout, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int probe_spill(pt_scene* s, int n, int32_t*& spill) {
+    spill = nullptr;
+    if (s->ds.stackSpill > 0) {
+        if (int r = s->spill.ensure((size_t)probe_trace_blocks(n) * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
+        spill = (int32_t*)s->spill.p;
+    }
+    return 0;
+}
+
+int pt_probe_trace_closest(pt_scene* s, int n, const float* rays6, int32_t* outI, float* outF, pt_counters* counters) {
+    if (!s || n <= 0) return fail(-1, "bad arguments");
+    Scratch sc;
+    SCRATCH(dr, float, (size_t)n * 24, rays6);
+    SCRATCH(di, int32_t, (size_t)n * 16, nullptr);
+    SCRATCH(df, float, (size_t)n * 48, nullptr);
+    SCRATCH(dt, unsigned long long, 64, nullptr);
+    HIP_OK(hipMemset(dt, 0, 64));
+    int32_t* spill; if (int r = probe_spill(s, n, spill)) return r;
+    HIP_OK(launch_probe_closest(s->ds, n, dr, di, df, dt, spill, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(outI, di, (size_t)n * 16, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(outF, df, (size_t)n * 48, hipMemcpyDeviceToHost));
+    if (counters) HIP_OK(hipMemcpy(counters, dt, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_trace_shadow(pt_scene* s, int n, const float* rays6, const float* maxT, float* outThr3, pt_counters* counters) {
+    if (!s || n <= 0) return fail(-1, "bad arguments");
+    Scratch sc;
+    SCRATCH(dr, float, (size_t)n * 24, rays6);
+    SCRATCH(dm, float, (size_t)n * 4, maxT);
+    SCRATCH(df, float, (size_t)n * 12, nullptr);
+    SCRATCH(dt, unsigned long long, 64, nullptr);
+    HIP_OK(hipMemset(dt, 0, 64));
+    int32_t* spill; if (int r = probe_spill(s, n, spill)) return r;
+    HIP_OK(launch_probe_shadow(s->ds, n, dr, dm, df, dt, spill, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(outThr3, df, (size_t)n * 12, hipMemcpyDeviceToHost));
+    if (counters) HIP_OK(hipMemcpy(counters, dt, 64, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_bsdf_sample(pt_scene* s, int n, const int32_t* material, const float* wi3, const int32_t* backface, float etaI, float etaT,
+                         uint64_t seed, const uint32_t* subseq, float* out8) {
+    (void)etaT;      // the reference's sample_f_eval never reads etaT (reflectors.cuh:588-629)
+    if (!s || n <= 0) return fail(-1, "bad arguments");
+    Scratch sc;
+    const uint32_t* dj; if (int r = jump_device(sc, dj)) return r;
+    SCRATCH(dsub, uint32_t, (size_t)n * 4, subseq);
+    SCRATCH(dst, uint32_t, (size_t)n * 24, nullptr);
+    SCRATCH(du, uint32_t, 16, nullptr);
+    SCRATCH(dfu, float, 16, nullptr);
+    SCRATCH(dm, int, (size_t)n * 4, material);
+    SCRATCH(dw, float, (size_t)n * 12, wi3);
+    SCRATCH(db, int, (size_t)n * 4, backface);
+    SCRATCH(dout, float, (size_t)n * 32, nullptr);
+    HIP_OK(launch_probe_rng(dj, seed, n, dsub, 0, dst, du, dfu, nullptr));
+    HIP_OK(launch_probe_bsdf_sample(s->ds, n, dm, dw, db, etaI, dst, dout, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out8, dout, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_bsdf_eval(pt_scene* s, int n, const int32_t* material, const float* wi3, const float* wo3, float etaI, float etaT, float* out4) {
+    (void)etaT;
+    if (!s || n <= 0) return fail(-1, "bad arguments");
+    Scratch sc;
+    SCRATCH(dm, int, (size_t)n * 4, material);
+    SCRATCH(dwi, float, (size_t)n * 12, wi3);
+    SCRATCH(dwo, float, (size_t)n * 12, wo3);
+    SCRATCH(dout, float, (size_t)n * 16, nullptr);
+    HIP_OK(launch_probe_bsdf_eval(s->ds, n, dm, dwi, dwo, etaI, dout, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out4, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

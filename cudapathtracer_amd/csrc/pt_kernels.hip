@@ -1,0 +1,533 @@
+// pt_kernels.hip — gfx950 kernels of the unidirectional path tracer.
+//
+//   rng_init_kernel     initRNG (deviceCode.cu:53-61): one XORWOW stream per pixel, keyed by the
+//                       global pixel index, via 2^67-step GF(2) jump matrices.
+//   megakernel          Li_unidirectional (deviceCode.cu:285-542) / Li_naive_unidirectional
+//                       (:158-205) with the reference's host sample loop (:568-573) INSIDE the
+//                       kernel: RNG state and the accumulator stay in registers for all spp, so
+//                       the reference's 128 B/pixel/sample of global traffic becomes 40 B/pixel.
+//   tile / untile       8x8 tile-major <-> scan-line framebuffer.
+//   probe_*             single stages for known-answer tests.
+//
+// Execution shape: one wave64 owns one 8x8-pixel tile (lane = ly*8+lx); a 256-thread workgroup
+// is four independent waves (no barriers). Every lane walks its pixel's samples in order (the
+// per-pixel stream is sequential by construction) and lanes REGENERATE: a lane whose path
+// ended starts its pixel's next sample at the top of the next bounce iteration, so the wave
+// keeps 64 live rays for traversal until the pixels run out of samples; the wave leaves the loop
+// when a ballot finds no live lane.
+#include "pt_shade.h"
+#include "pt_params.h"
+
+namespace pt {
+
+
+PT_DEV void wave_add_total(unsigned long long* totals, int k, uint32_t v) {
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&totals[k], s);
+}
+
+// -------------------------------------------------------------------------------------------
+// jump: [32][160][5] words, jump[k] = A^(2^67 * 2^k) in row-image form. Lane state v <- M v is
+// the XOR of the rows selected by v's set bits; the row address is wave-uniform (scalar loads).
+__global__ void __launch_bounds__(256) rng_init_kernel(const uint32_t* __restrict__ jump, unsigned long long seed, int w, int h,
+                                                       int tileFirst, int tileStride, int tileCount, int tilesX, uint32_t* __restrict__ rng) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int lt = blockIdx.x * 4 + wave;
+    if (lt >= tileCount) return;
+    int tile = tileFirst + lt * tileStride;
+    int x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    uint32_t d = 6615241u + t1 + t0;
+    uint32_t idx = (x < w && y < h) ? (uint32_t)(y * w + x) : 0u;
+    for (int k = 0; k < 32; k++) {
+        if (!__ballot((idx >> k) & 1u)) continue;
+        if ((idx >> k) & 1u) {
+            const uint32_t* M = jump + (size_t)k * 800;
+            uint32_t r[5] = {0, 0, 0, 0, 0};
+            for (int i = 0; i < 5; i++) {
+                uint32_t word = v[i];
+                for (int j = 0; j < 32; j++) {
+                    uint32_t m = 0u - ((word >> j) & 1u);
+                    const uint32_t* row = M + (i * 32 + j) * 5;
+                    r[0] ^= row[0] & m; r[1] ^= row[1] & m; r[2] ^= row[2] & m; r[3] ^= row[3] & m; r[4] ^= row[4] & m;
+                }
+            }
+            for (int i = 0; i < 5; i++) v[i] = r[i];
+        }
+    }
+    uint32_t* o = rng + (size_t)lt * 384 + lane;
+    o[0] = v[0]; o[64] = v[1]; o[128] = v[2]; o[192] = v[3]; o[256] = v[4]; o[320] = d;
+}
+
+// -------------------------------------------------------------------------------------------
+struct HitInfo { V3 point, normal, emission; float uvx, uvy, dist; int tri, material, lightInd; bool backface; };
+
+// The attribute block of BVHSceneIntersect (integratorUtilities.cuh:113-141) for the final hit.
+PT_DEV void resolve_hit(const DeviceScene& S, const Hit& h, V3 o, V3 d, HitInfo& hi) {
+    const PAttr& at = S.attrs[h.tri];
+    float bz = 1.0f - h.u - h.v;
+    hi.point = v3(__builtin_fmaf(h.t, d.x, o.x), __builtin_fmaf(h.t, d.y, o.y), __builtin_fmaf(h.t, d.z, o.z));
+    V3 n = normalize(ld3(at.n0) * bz + ld3(at.n1) * h.u + ld3(at.n2) * h.v);
+    hi.uvx = at.uv0[0] * bz + at.uv1[0] * h.u + at.uv2[0] * h.v;
+    hi.uvy = at.uv0[1] * bz + at.uv1[1] * h.u + at.uv2[1] * h.v;
+    if (dot(n, d) > 0.0f) { n = -n; hi.backface = true; } else hi.backface = false;
+    hi.normal = n;
+    hi.material = at.material;
+    hi.emission = ld3(at.emission);
+    hi.lightInd = at.lightInd;
+    hi.tri = h.tri;
+    hi.dist = h.t;
+}
+
+// removeMaterialFromStack, integratorUtilities.cuh:414-434 (entry 0 is never removed)
+PT_DEV void medium_remove(uint8_t* ms, int& top, int materialID) {
+    int found = -1;
+    for (int i = top - 1; i > 0; i--) if (ms[i * 64] == materialID) { found = i; break; }
+    if (found != -1) {
+        for (int i = found; i < top - 1; i++) ms[i * 64] = ms[(i + 1) * 64];
+        top--;
+    }
+}
+
+template <int INTEG, bool COUNT>
+__global__ void __launch_bounds__(256) megakernel(KParams P) {
+    __shared__ int32_t ldsStack[4][kStackLds][64];
+    __shared__ uint8_t ldsMedium[4][kMediumMax][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lt = blockIdx.x * 4 + wave;
+    if (lt >= P.tileCount) return;
+    const DeviceScene& S = P.S;
+    const int tile = P.tileFirst + lt * P.tileStride;
+    const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
+    const bool inImage = (x < P.w) && (y < P.h);
+
+    Stack<kStackLds> st;
+    st.lds = &ldsStack[wave][0][lane];
+    st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
+    st.sp = 0;
+    uint8_t* ms = &ldsMedium[wave][0][lane];
+
+    Rng rng;
+    {
+        const uint32_t* r = P.rng + (size_t)lt * 384 + lane;
+        rng.v0 = r[0]; rng.v1 = r[64]; rng.v2 = r[128]; rng.v3 = r[192]; rng.v4 = r[256]; rng.d = r[320];
+    }
+    float4 acc4 = P.out[(size_t)lt * 64 + lane];
+    V3 acc = v3(acc4.x, acc4.y, acc4.z);
+    Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    int samplesLeft = inImage ? P.spp : 0;
+    bool inPath = false;
+    // path state
+    V3 o = v3(0.0f), d = v3(0.0f), beta = v3(1.0f), Li = v3(0.0f), prevPoint = v3(0.0f), woLocal = v3(0.0f);
+    float pdf = kEps, etaI = kEps, etaT = kEps;
+    int depth = 0, guard = 0, msTop = 1;
+    bool hitFirstNonSpecular = false;
+    const int depthLimit = (INTEG == 2) ? P.maxDepth : 100;
+
+    while (true) {
+        if (!inPath && samplesLeft > 0) {
+            samplesLeft--;
+            inPath = true;
+            camera_ray<COUNT>(P.cam, rng, x, y, o, d, c);
+            beta = v3(1.0f); Li = v3(0.0f); prevPoint = v3(0.0f); woLocal = v3(0.0f);
+            pdf = kEps; etaI = kEps; etaT = kEps;
+            depth = 0; guard = 0; msTop = 1; ms[0] = 0;
+            hitFirstNonSpecular = false;
+        }
+        if (__ballot(inPath) == 0ull) break;
+        if (!inPath) continue;
+
+        bool done = false;
+        if (depth >= depthLimit) done = true;
+        else if (INTEG != 2 && ++guard > 4096) done = true;
+        if (!done) {
+            if (COUNT) c.iters++;
+            Hit h;
+            trace_closest<COUNT, kStackLds>(S, o, d, 999999.0f, st, h, c);
+            if (h.tri < 0) {
+                Li = Li + beta * v3(0.0f);             // `Li += beta * sampleSky()`; the sky is black (integratorUtilities.cuh:436-438)
+                done = true;
+            } else {
+                HitInfo hi;
+                resolve_hit(S, h, o, d, hi);
+                const PMat& m = S.mats[hi.material];
+                if (INTEG == 2) {
+                    // ---- Li_naive_unidirectional, deviceCode.cu:172-202 ----
+                    V3 toSurface = to_local(d, hi.normal);
+                    V3 f = v3(0.0f), toNext = v3(0.0f);
+                    float p = 0.0f;
+                    sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
+                    if (p <= 0.0f || dot(f, f) < kEps) done = true;
+                    else {
+                        Li = Li + hi.emission * beta;
+                        beta = beta * ((f * __builtin_fabsf(toNext.z)) / p);
+                        V3 nw = to_world(toNext, hi.normal);
+                        o = hi.point + ((toNext.z > 0.0f) ? (hi.normal * kRayEps) : ((-hi.normal) * kRayEps));
+                        d = nw;
+                        depth++;
+                    }
+                } else {
+                    // ---- Li_unidirectional, deviceCode.cu:332-537 ----
+                    V3 wiLocal = to_local(d, hi.normal);
+                    bool isSpecular = (m.flags & kMatSpecular) != 0;
+                    bool trueHit = true;
+                    int minPrior = S.mats[ms[0]].priority, minPriorID = ms[0];
+                    for (int i = 1; i < msTop; i++) {
+                        int id = ms[i * 64];
+                        int pr = S.mats[id].priority;
+                        if (pr < minPrior) { minPrior = pr; minPriorID = id; }
+                    }
+                    const PMat& dom = S.mats[minPriorID];
+                    if (hi.dist > kEps) {
+                        V3 att = v3(exp_(-dom.absorption[0] * hi.dist), exp_(-dom.absorption[1] * hi.dist), exp_(-dom.absorption[2] * hi.dist));
+                        beta = beta * att;
+                    }
+                    if (m.flags & kMatBoundary) {
+                        if (m.priority <= minPrior) {
+                            if (m.type == 2) {
+                                etaI = dom.ior;
+                                if (!hi.backface) etaT = m.ior;
+                                else if (msTop == 1) etaT = 1.0f;
+                                else {
+                                    int mp = 99, second = ms[0];
+                                    for (int i = 0; i < msTop; i++) {
+                                        int id = ms[i * 64];
+                                        int pr = S.mats[id].priority;
+                                        if (pr) { if (mp > pr && id != hi.material) { second = id; mp = pr; } }
+                                    }
+                                    etaT = S.mats[second].ior;
+                                }
+                            }
+                        } else {
+                            trueHit = false;
+                            if (!hi.backface) { if (msTop < kMediumMax) { ms[msTop * 64] = (uint8_t)hi.material; msTop++; } }
+                            else medium_remove(ms, msTop, hi.material);
+                        }
+                    } else etaI = dom.ior;
+
+                    if (trueHit) {
+                        float le2 = dot(hi.emission, hi.emission);
+                        if (le2 > kEps) {
+                            if (depth == 0 || !hitFirstNonSpecular) Li = Li + beta * hi.emission;
+                            else if (P.useMIS && !isSpecular) {
+                                // neePDF, deviceCode.cu:63-85: the hit triangle as a light
+                                float lightPdf = kEps;
+                                if (hi.lightInd >= 0) {
+                                    const PLight& L = S.lights[hi.lightInd];
+                                    V3 s2l = hi.point - prevPoint;
+                                    V3 wi = normalize(s2l);
+                                    float dist2 = dot(s2l, s2l);
+                                    float cosL = dot(ld3(L.na), -wi);
+                                    float area = 0.5f * length(cross(ld3(L.b) - ld3(L.a), ld3(L.c) - ld3(L.a)));
+                                    lightPdf = dist2 / (cosL * (float)S.nLights * area);
+                                }
+                                if (lightPdf > kEps) {
+                                    float wB = pdf * pdf / (lightPdf * lightPdf + pdf * pdf);
+                                    Li = Li + (beta * hi.emission) * wB;
+                                }
+                            }
+                        }
+                        if (P.useMIS && le2 < kEps && !isSpecular) {
+                            // nextEventEstimation, deviceCode.cu:87-156
+                            float lightPdf = kEps;
+                            V3 nee = v3(0.0f);
+                            if (S.nLights == 0) lightPdf = -1.0f;
+                            else {
+                                int index = min((int)(draw<COUNT>(rng, c) * (float)S.nLights), S.nLights - 1);
+                                const PLight& L = S.lights[index];
+                                V3 A = ld3(L.a), B = ld3(L.b), C = ld3(L.c);
+                                float u = __builtin_sqrtf(draw<COUNT>(rng, c));
+                                float v = draw<COUNT>(rng, c);
+                                V3 p = (1.0f - u) * A + (u * (1.0f - v)) * B + (u * v) * C;
+                                V3 s2l = p - hi.point;
+                                V3 wi = normalize(s2l);
+                                V3 ro = hi.point + wi * kEps;
+                                // t to the light triangle; if that test fails the reference leaves t
+                                // uninitialised (:121-123) — defined as |s2l| - EPSILON
+                                float t = length(s2l) - kEps;
+                                {
+                                    float tt, uu, vv;
+                                    if (moller_trumbore(A, B - A, C - A, ro, wi, tt, uu, vv)) t = tt;
+                                }
+                                V3 thr = trace_shadow<COUNT, kStackLds>(S, ro, wi, t * (1.0f - kEps), st, c);
+                                if (dot(thr, thr) > 0.0f) {
+                                    float dist2 = dot(s2l, s2l);
+                                    float cosL = dot(ld3(L.na), -wi);
+                                    float cosS = __builtin_fabsf(dot(hi.normal, wi));
+                                    float area = 0.5f * length(cross(B - A, C - A));
+                                    lightPdf = dist2 / (cosL * (float)S.nLights * area);
+                                    V3 wiL = to_local(wi, hi.normal);
+                                    woLocal = wiL;
+                                    V3 f = f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
+                                    nee = ((f * ld3(L.emission)) * cosS) / lightPdf;
+                                    nee = nee * thr;
+                                }
+                            }
+                            if (lightPdf > kEps) {
+                                pdf_eval(m, S.textures, wiLocal, woLocal, etaI, hi.uvx, hi.uvy, pdf);
+                                float wN = lightPdf * lightPdf / (pdf * pdf + lightPdf * lightPdf);
+                                Li = Li + (beta * nee) * wN;
+                            }
+                        }
+                        V3 f = v3(0.0f);
+                        sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
+                        V3 woWorld = to_world(woLocal, hi.normal);
+                        pdf = fmaxf_(pdf, 0.01f);
+                        if (woLocal.z < 0.0f) {
+                            if (!hi.backface) { if (msTop < kMediumMax) { ms[msTop * 64] = (uint8_t)hi.material; msTop++; } }
+                            else medium_remove(ms, msTop, hi.material);
+                        }
+                        beta = beta * ((f * __builtin_fabsf(woLocal.z)) / pdf);
+                        if (woLocal.z > 0.0f) o = hi.point + hi.normal * kEps;
+                        else o = hi.point - hi.normal * kEps;
+                        d = normalize(woWorld);
+                        prevPoint = hi.point;
+                    } else {
+                        woLocal = to_local(d, hi.normal);
+                        o = hi.point + d * kRayEps;
+                        depth--;
+                    }
+                    if (depth > P.maxDepth) {
+                        float lum = dot(beta, v3(0.2126f, 0.7152f, 0.0722f));
+                        float p = clampf(lum, 0.05f, 0.99f);
+                        if (draw<COUNT>(rng, c) > p) done = true;
+                        else beta = beta / p;
+                    }
+                    if (!done) {
+                        if (!isSpecular) hitFirstNonSpecular = true;
+                        depth++;
+                    }
+                }
+            }
+        }
+        if (done) {
+            acc = acc + Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
+            inPath = false;
+        }
+    }
+
+    if (inImage) P.out[(size_t)lt * 64 + lane] = make_float4(acc.x, acc.y, acc.z, acc4.w);
+    {
+        uint32_t* r = P.rng + (size_t)lt * 384 + lane;
+        r[0] = rng.v0; r[64] = rng.v1; r[128] = rng.v2; r[192] = rng.v3; r[256] = rng.v4; r[320] = rng.d;
+    }
+    if (COUNT) {
+        if (P.pixCounters) {
+            uint32_t* pc = P.pixCounters + (size_t)lt * 512 + lane;
+            pc[0] = c.raysClosest; pc[64] = c.raysShadow; pc[128] = c.pops; pc[192] = c.boxes;
+            pc[256] = c.tris; pc[320] = c.hits; pc[384] = c.draws; pc[448] = c.iters;
+        }
+        if (P.totals) {
+            wave_add_total(P.totals, 0, c.raysClosest); wave_add_total(P.totals, 1, c.raysShadow);
+            wave_add_total(P.totals, 2, c.pops); wave_add_total(P.totals, 3, c.boxes);
+            wave_add_total(P.totals, 4, c.tris); wave_add_total(P.totals, 5, c.hits);
+            wave_add_total(P.totals, 6, c.draws); wave_add_total(P.totals, 7, c.iters);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// tile-major [local tile][64] <-> scan-line colors[y*w+x]
+__global__ void __launch_bounds__(256) untile_kernel(int w, int h, int tileFirst, int tileStride, int tileCount, int tilesX,
+                                                     const float4* __restrict__ tiles, float4* __restrict__ colors) {
+    int lt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (lt >= tileCount) return;
+    int tile = tileFirst + lt * tileStride;
+    int x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    if (x < w && y < h) colors[(size_t)y * w + x] = tiles[(size_t)lt * 64 + lane];
+}
+__global__ void __launch_bounds__(256) tile_kernel(int w, int h, int tileFirst, int tileStride, int tileCount, int tilesX,
+                                                   const float4* __restrict__ colors, float4* __restrict__ tiles) {
+    int lt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (lt >= tileCount) return;
+    int tile = tileFirst + lt * tileStride;
+    int x = (tile % tilesX) * 8 + (lane & 7), y = (tile / tilesX) * 8 + (lane >> 3);
+    tiles[(size_t)lt * 64 + lane] = (x < w && y < h) ? colors[(size_t)y * w + x] : make_float4(0, 0, 0, 0);
+}
+
+// ---- probes ---------------------------------------------------------------------------------
+__global__ void probe_rng_kernel(const uint32_t* __restrict__ jump, unsigned long long seed, int n, const uint32_t* __restrict__ subseq,
+                                 int nDraws, uint32_t* outState, uint32_t* outU32, float* outUni) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    uint32_t d = 6615241u + t1 + t0;
+    uint32_t idx = subseq[i];
+    for (int k = 0; k < 32; k++) {
+        if (!((idx >> k) & 1u)) continue;
+        const uint32_t* M = jump + (size_t)k * 800;
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < 160; b++) {
+            uint32_t m = 0u - ((v[b >> 5] >> (b & 31)) & 1u);
+            for (int q = 0; q < 5; q++) r[q] ^= M[b * 5 + q] & m;
+        }
+        for (int q = 0; q < 5; q++) v[q] = r[q];
+    }
+    for (int q = 0; q < 5; q++) outState[i * 6 + q] = v[q];
+    outState[i * 6 + 5] = d;
+    Rng a = {v[0], v[1], v[2], v[3], v[4], d}, b = a;
+    for (int k = 0; k < nDraws; k++) { outU32[i * nDraws + k] = rng_next(a); outUni[i * nDraws + k] = rng_uniform(b); }
+}
+
+__global__ void probe_math_kernel(int n, const float* x, float* s, float* cth, float* e, float* rs, float* p5) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs; sincos_(x[i], sn, cs);
+    s[i] = sn; cth[i] = cs; e[i] = exp_(x[i]); rs[i] = rsqrt_(x[i]); p5[i] = pow5_(x[i]);
+}
+
+__global__ void probe_camera_kernel(const uint32_t* __restrict__ state6, CamK cam, int n, const int* xy, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = {state6[i * 6], state6[i * 6 + 1], state6[i * 6 + 2], state6[i * 6 + 3], state6[i * 6 + 4], state6[i * 6 + 5]};
+    Ctr c = {};
+    V3 o, d;
+    camera_ray<false>(cam, r, xy[2 * i], xy[2 * i + 1], o, d, c);
+    out[6 * i] = o.x; out[6 * i + 1] = o.y; out[6 * i + 2] = o.z; out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
+}
+
+__global__ void __launch_bounds__(64) probe_closest_kernel(DeviceScene S, int n, const float* rays, int32_t* outI, float* outF,
+                                                           unsigned long long* totals, int32_t* spill) {
+    __shared__ int32_t ldsStack[kStackLds][64];
+    int i = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
+    Stack<kStackLds> st; st.lds = &ldsStack[0][lane]; st.sp = 0;
+    st.spill = spill ? spill + ((size_t)blockIdx.x * S.stackSpill) * 64 + lane : nullptr;
+    Ctr c = {};
+    if (i < n) {
+        V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        Hit h;
+        trace_closest<true, kStackLds>(S, o, d, 999999.0f, st, h, c);
+        float* f = outF + 12 * i;
+        for (int k = 0; k < 12; k++) f[k] = 0.0f;
+        if (h.tri >= 0) {
+            HitInfo hi; resolve_hit(S, h, o, d, hi);
+            outI[4 * i] = 1; outI[4 * i + 1] = hi.tri; outI[4 * i + 2] = hi.material; outI[4 * i + 3] = hi.backface;
+            f[0] = h.t; f[1] = h.u; f[2] = h.v; f[3] = hi.point.x; f[4] = hi.point.y; f[5] = hi.point.z;
+            f[6] = hi.normal.x; f[7] = hi.normal.y; f[8] = hi.normal.z; f[9] = hi.uvx; f[10] = hi.uvy;
+        } else { outI[4 * i] = 0; outI[4 * i + 1] = -1; outI[4 * i + 2] = -1; outI[4 * i + 3] = 0; }
+    }
+    wave_add_total(totals, 0, c.raysClosest); wave_add_total(totals, 1, c.raysShadow); wave_add_total(totals, 2, c.pops);
+    wave_add_total(totals, 3, c.boxes); wave_add_total(totals, 4, c.tris); wave_add_total(totals, 5, c.hits);
+}
+
+__global__ void __launch_bounds__(64) probe_shadow_kernel(DeviceScene S, int n, const float* rays, const float* maxT, float* outF,
+                                                          unsigned long long* totals, int32_t* spill) {
+    __shared__ int32_t ldsStack[kStackLds][64];
+    int i = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
+    Stack<kStackLds> st; st.lds = &ldsStack[0][lane]; st.sp = 0;
+    st.spill = spill ? spill + ((size_t)blockIdx.x * S.stackSpill) * 64 + lane : nullptr;
+    Ctr c = {};
+    if (i < n) {
+        V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        V3 t = trace_shadow<true, kStackLds>(S, o, d, maxT[i], st, c);
+        outF[3 * i] = t.x; outF[3 * i + 1] = t.y; outF[3 * i + 2] = t.z;
+    }
+    wave_add_total(totals, 0, c.raysClosest); wave_add_total(totals, 1, c.raysShadow); wave_add_total(totals, 2, c.pops);
+    wave_add_total(totals, 3, c.boxes); wave_add_total(totals, 4, c.tris); wave_add_total(totals, 5, c.hits);
+}
+
+__global__ void probe_bsdf_sample_kernel(DeviceScene S, int n, const int* material, const float* wi3, const int* backface, float etaI,
+                                         const uint32_t* __restrict__ state6, float* out8) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = {state6[i * 6], state6[i * 6 + 1], state6[i * 6 + 2], state6[i * 6 + 3], state6[i * 6 + 4], state6[i * 6 + 5]};
+    Ctr c = {};
+    V3 wo = v3(0.0f), f = v3(0.0f); float pdf = 0.0f;
+    sample_f_eval<true>(r, S.mats[material[i]], S.textures, v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), etaI, backface[i] != 0, wo, f, pdf, 0.0f, 0.0f, c);
+    float* o = out8 + 8 * i;
+    o[0] = wo.x; o[1] = wo.y; o[2] = wo.z; o[3] = f.x; o[4] = f.y; o[5] = f.z; o[6] = pdf; o[7] = (float)c.draws;
+}
+
+__global__ void probe_bsdf_eval_kernel(DeviceScene S, int n, const int* material, const float* wi3, const float* wo3, float etaI, float* out4) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PMat& m = S.mats[material[i]];
+    V3 wi = v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]), wo = v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+    V3 f = f_eval(m, S.textures, wi, wo, etaI, 0.0f, 0.0f);
+    float pdf = 0.0f;
+    pdf_eval(m, S.textures, wi, wo, etaI, 0.0f, 0.0f, pdf);
+    out4[4 * i] = f.x; out4[4 * i + 1] = f.y; out4[4 * i + 2] = f.z; out4[4 * i + 3] = pdf;
+}
+
+}  // namespace pt
+
+// ---- host-callable launchers ---------------------------------------------------------------
+namespace pt {
+
+hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w, int h, TileSpan t, uint32_t* rng, hipStream_t stream) {
+    if (t.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rng_init_kernel, dim3((t.count + 3) / 4), dim3(256), 0, stream, jump, seed, w, h, t.first, t.stride, t.count, t.tilesX, rng);
+    return hipGetLastError();
+}
+
+hipError_t launch_megakernel(int integrator, bool count, const KParams& P, hipStream_t stream) {
+    if (P.tileCount <= 0) return hipSuccess;
+    dim3 grid(megakernel_blocks(P.tileCount)), block(256);
+    if (integrator == 2) {
+        if (count) hipLaunchKernelGGL((megakernel<2, true>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((megakernel<2, false>), grid, block, 0, stream, P);
+    } else {
+        if (count) hipLaunchKernelGGL((megakernel<0, true>), grid, block, 0, stream, P);
+        else hipLaunchKernelGGL((megakernel<0, false>), grid, block, 0, stream, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_untile(int w, int h, TileSpan t, const float4* tiles, float4* colors, hipStream_t stream) {
+    if (t.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(untile_kernel, dim3((t.count + 3) / 4), dim3(256), 0, stream, w, h, t.first, t.stride, t.count, t.tilesX, tiles, colors);
+    return hipGetLastError();
+}
+hipError_t launch_tile(int w, int h, TileSpan t, const float4* colors, float4* tiles, hipStream_t stream) {
+    if (t.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_kernel, dim3((t.count + 3) / 4), dim3(256), 0, stream, w, h, t.first, t.stride, t.count, t.tilesX, colors, tiles);
+    return hipGetLastError();
+}
+hipError_t launch_probe_rng(const uint32_t* jump, unsigned long long seed, int n, const uint32_t* subseq, int nDraws,
+                            uint32_t* outState, uint32_t* outU32, float* outUni, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_rng_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, jump, seed, n, subseq, nDraws, outState, outU32, outUni);
+    return hipGetLastError();
+}
+hipError_t launch_probe_math(int n, const float* x, float* s, float* c, float* e, float* rs, float* p5, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, s, c, e, rs, p5);
+    return hipGetLastError();
+}
+hipError_t launch_probe_camera(const uint32_t* state6, const CamK& cam, int n, const int* xy, float* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_camera_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, state6, cam, n, xy, out);
+    return hipGetLastError();
+}
+hipError_t launch_probe_closest(const DeviceScene& S, int n, const float* rays, int32_t* outI, float* outF,
+                                unsigned long long* totals, int32_t* spill, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_closest_kernel, dim3(probe_trace_blocks(n)), dim3(64), 0, stream, S, n, rays, outI, outF, totals, spill);
+    return hipGetLastError();
+}
+hipError_t launch_probe_shadow(const DeviceScene& S, int n, const float* rays, const float* maxT, float* outF,
+                               unsigned long long* totals, int32_t* spill, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_shadow_kernel, dim3(probe_trace_blocks(n)), dim3(64), 0, stream, S, n, rays, maxT, outF, totals, spill);
+    return hipGetLastError();
+}
+hipError_t launch_probe_bsdf_sample(const DeviceScene& S, int n, const int* material, const float* wi3, const int* backface, float etaI,
+                                    const uint32_t* state6, float* out8, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_bsdf_sample_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, n, material, wi3, backface, etaI, state6, out8);
+    return hipGetLastError();
+}
+hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* material, const float* wi3, const float* wo3, float etaI,
+                                  float* out4, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(probe_bsdf_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, n, material, wi3, wo3, etaI, out4);
+    return hipGetLastError();
+}
+
+}  // namespace pt

@@ -1,0 +1,46 @@
+// pt_params.h — kernel parameter blocks and host-callable launchers shared by pt_kernels.hip
+// (definitions) and pt_api.hip (C ABI).
+#pragma once
+#include "pt_device.h"
+
+namespace pt {
+
+constexpr int kStackLds = 32;     // LDS traversal-stack entries per lane (8 KiB per wave)
+constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
+
+struct KParams {
+    DeviceScene S;
+    CamK cam;
+    int w, h, spp, maxDepth, useMIS;
+    int tileFirst, tileStride, tileCount, tilesX;
+    uint32_t* rng;                 // [tile][6][64]
+    float4* out;                   // [tile][64], += semantics
+    uint32_t* pixCounters;         // [tile][8][64] or null
+    unsigned long long* totals;    // 8 x u64 or null
+    int32_t* spill;                // [wave slot][entry][64] or null
+};
+
+struct TileSpan { int first, stride, count, tilesX; };
+
+// Launchers (asynchronous on `stream`); defined in pt_kernels.hip.
+hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w, int h, TileSpan t, uint32_t* rng, hipStream_t stream);
+hipError_t launch_megakernel(int integrator, bool count, const KParams& P, hipStream_t stream);
+hipError_t launch_untile(int w, int h, TileSpan t, const float4* tiles, float4* colors, hipStream_t stream);
+hipError_t launch_tile(int w, int h, TileSpan t, const float4* colors, float4* tiles, hipStream_t stream);
+hipError_t launch_probe_rng(const uint32_t* jump, unsigned long long seed, int n, const uint32_t* subseq, int nDraws,
+                            uint32_t* outState, uint32_t* outU32, float* outUni, hipStream_t stream);
+hipError_t launch_probe_math(int n, const float* x, float* s, float* c, float* e, float* rs, float* p5, hipStream_t stream);
+hipError_t launch_probe_camera(const uint32_t* state6, const CamK& cam, int n, const int* xy, float* out, hipStream_t stream);
+hipError_t launch_probe_closest(const DeviceScene& S, int n, const float* rays, int32_t* outI, float* outF,
+                                unsigned long long* totals, int32_t* spill, hipStream_t stream);
+hipError_t launch_probe_shadow(const DeviceScene& S, int n, const float* rays, const float* maxT, float* outF,
+                               unsigned long long* totals, int32_t* spill, hipStream_t stream);
+hipError_t launch_probe_bsdf_sample(const DeviceScene& S, int n, const int* material, const float* wi3, const int* backface, float etaI,
+                                    const uint32_t* state6, float* out8, hipStream_t stream);
+hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* material, const float* wi3, const float* wo3, float etaI,
+                                  float* out4, hipStream_t stream);
+// waves a probe_closest/shadow launch of n rays uses (spill sizing)
+inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
+inline int megakernel_blocks(int tileCount) { return (tileCount + 3) / 4; }
+
+}  // namespace pt

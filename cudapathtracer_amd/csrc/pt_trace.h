@@ -1,0 +1,184 @@
+// pt_trace.h — BVH traversal for gfx950: one ray per lane, traversal stack in LDS.
+//
+// Replaces BVHSceneIntersect / BVHShadowRay / triangleIntersect / aabbIntersect of the
+// reference (integratorUtilities.cuh:8-288) with the same visiting order and the same
+// arithmetic, on a re-packed tree:
+//   * an internal node record (PNode, 64 B) carries BOTH children's boxes, so one fetch
+//     replaces the reference's parent + two child-node fetches;
+//   * leaves are not nodes: a negative child ref points straight at the first packed
+//     triangle (PTri, 48 B, pre-gathered in BVHindices order, edges pre-subtracted), and a
+//     flag on the triangle ends the leaf — no index indirection, no Vertices double hop;
+//   * 1/dir is computed once per ray (the reference recomputes it per box, :50-55; same value);
+//   * the nearer child is kept in a register instead of being pushed and popped again (the
+//     reference pushes far then near and immediately pops near, :161-173; same order);
+//   * hit attributes are interpolated once, for the final hit (the reference does it on
+//     every improving hit, :113-141; same value, it is a pure function of the winner).
+// Visiting order, tie rules (`tminL < tminR` else right first; strict `t < min_t`) and the
+// per-ray counters are exactly the reference's.
+#pragma once
+#include "pt_device.h"
+
+namespace pt {
+
+struct Ctr { uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters; };
+
+// Per-lane traversal stack: N entries in LDS (lane-interleaved: entry k of lane l lives at
+// word k*64 + l, so every access is bank-conflict-free), overflow in a global spill area with
+// the same interleave. The host sizes the spill from the tree depth; Cornell-class trees never
+// reach it.
+template <int N>
+struct Stack {
+    int32_t* lds;
+    int32_t* spill;
+    int sp;
+    PT_DEV void push(int32_t v) {
+        if (sp < N) lds[sp * 64] = v; else spill[(sp - N) * 64] = v;
+        sp++;
+    }
+    PT_DEV int32_t pop() {
+        sp--;
+        return sp < N ? lds[sp * 64] : spill[(sp - N) * 64];
+    }
+};
+
+struct Hit { float t, u, v; int32_t tri; int32_t material; };
+
+// aabbIntersect (integratorUtilities.cuh:44-82) with a hoisted reciprocal direction.
+PT_DEV bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, V3 o, V3 inv, float& tmin) {
+    float tx1 = (mnx - o.x) * inv.x, tx2 = (mxx - o.x) * inv.x;
+    float tmn = fmaxf_(-1e30f, fminf_(tx1, tx2));
+    float tmx = fminf_(1e30f, fmaxf_(tx1, tx2));
+    float ty1 = (mny - o.y) * inv.y, ty2 = (mxy - o.y) * inv.y;
+    tmn = fmaxf_(tmn, fminf_(ty1, ty2));
+    tmx = fminf_(tmx, fmaxf_(ty1, ty2));
+    float tz1 = (mnz - o.z) * inv.z, tz2 = (mxz - o.z) * inv.z;
+    tmn = fmaxf_(tmn, fminf_(tz1, tz2));
+    tmx = fminf_(tmx, fmaxf_(tz1, tz2));
+    tmin = tmn;
+    return (tmx >= tmn) && (tmx > 0.0f);
+}
+
+// triangleIntersect (integratorUtilities.cuh:8-42) on a packed triangle.
+PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u, float& v) {
+    V3 h = cross(d, e2);
+    float a = dot(h, e1);
+    if (__builtin_fabsf(a) < 1e-12f) return false;
+    float f = 1.0f / a;                    // == (float)(1.0 / (double)a), DESIGN.md §4
+    V3 s = o - v0;
+    u = f * dot(s, h);
+    V3 q = cross(s, e1);
+    v = f * dot(d, q);
+    t = f * dot(e2, q);
+    return ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f)) && t > 0.0f;
+}
+
+struct NodeData { float4 a, b, c, d; };
+PT_DEV NodeData load_node(const PNode* nodes, int32_t i) {
+    const float4* p = reinterpret_cast<const float4*>(nodes + i);
+    return NodeData{p[0], p[1], p[2], p[3]};
+}
+
+// One internal-node step shared by both traversals: returns the next ref to visit.
+template <bool COUNT, int N>
+PT_DEV int32_t descend(const DeviceScene& S, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c) {
+    NodeData n = load_node(S.nodes, cur);
+    if (COUNT) { c.pops++; c.boxes += 2; }
+    float tL, tR;
+    bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
+    bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);
+    int32_t left = __builtin_bit_cast(int32_t, n.d.x), right = __builtin_bit_cast(int32_t, n.d.y);
+    if (hL && hR) {
+        bool leftNear = tL < tR;
+        st.push(leftNear ? right : left);
+        return leftNear ? left : right;
+    }
+    if (hL) return left;
+    if (hR) return right;
+    return st.sp > 0 ? st.pop() : kRefNone;
+}
+
+// BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
+template <bool COUNT, int N>
+PT_DEV void trace_closest(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float min_t = 3.402823466e+38f;
+    hit.tri = -1;
+    st.sp = 0;
+    int32_t cur = S.rootRef;
+    if (COUNT) c.raysClosest++;
+    while (true) {
+        while (cur >= 0) cur = descend<COUNT, N>(S, cur, o, inv, st, c);
+        if (cur == kRefNone) break;
+        if (COUNT) c.pops++;
+        const PTri* tp = S.tris + (~cur);
+        uint32_t idx;
+        do {
+            const float4* q = reinterpret_cast<const float4*>(tp);
+            float4 a = q[0], b = q[1], e = q[2];
+            idx = __builtin_bit_cast(uint32_t, e.y);
+            if (COUNT) c.tris++;
+            float t, u, v;
+            bool ok = moller_trumbore(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, e.x), o, d, t, u, v);
+            if (ok && (t < min_t) && (t < max_t)) {
+                min_t = t;
+                hit.t = t; hit.u = u; hit.v = v;
+                hit.tri = (int32_t)(idx & 0x7fffffffu);
+                hit.material = __builtin_bit_cast(int32_t, e.z);
+            }
+            tp++;
+        } while (!(idx & 0x80000000u));
+        cur = st.sp > 0 ? st.pop() : kRefNone;
+    }
+    if (COUNT) { if (hit.tri >= 0) c.hits++; }
+}
+
+PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // reflectors.cuh:183-188
+    float R0 = (etaI - etaT) / (etaI + etaT);
+    R0 = R0 * R0;
+    return R0 + (1.0f - R0) * pow5_(1.0f - __builtin_fabsf(cosTheta));
+}
+
+// BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
+// triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
+template <bool COUNT, int N>
+PT_DEV V3 trace_shadow(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 thr = v3(1.0f);
+    st.sp = 0;
+    int32_t cur = S.rootRef;
+    if (COUNT) c.raysShadow++;
+    while (true) {
+        while (cur >= 0) cur = descend<COUNT, N>(S, cur, o, inv, st, c);
+        if (cur == kRefNone) break;
+        if (COUNT) c.pops++;
+        const PTri* tp = S.tris + (~cur);
+        uint32_t idx;
+        do {
+            const float4* q = reinterpret_cast<const float4*>(tp);
+            float4 a = q[0], b = q[1], e = q[2];
+            idx = __builtin_bit_cast(uint32_t, e.y);
+            if (COUNT) c.tris++;
+            float t, u, v;
+            bool ok = moller_trumbore(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, e.x), o, d, t, u, v);
+            if (ok && (t < max_t)) {
+                uint32_t flags = __builtin_bit_cast(uint32_t, e.w);
+                if (!(flags & 1u)) return v3(0.0f);
+                // MAT_LEAF (integratorUtilities.cuh:218-239)
+                const PMat& m = S.mats[__builtin_bit_cast(int32_t, e.z)];
+                const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                float bz = 1.0f - u - v;
+                V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                V3 s = ld3(m.albedo) * m.transmission * (1.0f - F);
+                thr = thr * s;
+                if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) return v3(0.0f);
+            }
+            tp++;
+        } while (!(idx & 0x80000000u));
+        cur = st.sp > 0 ? st.pop() : kRefNone;
+    }
+    return thr;
+}
+
+}  // namespace pt

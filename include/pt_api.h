@@ -1,0 +1,196 @@
+/* pt_api.h — C ABI of the MI355X-native unidirectional path tracer (libptamd.so).
+ *
+ * Drop-in boundary for ONE hot path of DanielQ-51/cudapathtracer: the integrator launchers
+ *     launch_unidirectional / launch_naive_unidirectional        (deviceCode.cuh:8-12,
+ *                                                                 bodies deviceCode.cu:544-620, 207-283)
+ * and the kernels under them (initRNG deviceCode.cu:53-61, Li_unidirectional :285-542,
+ * Li_naive_unidirectional :158-205). Everything here is plain C: pointers, sizes, PODs whose
+ * byte layouts equal the reference's CUDA structs, no torch / HIP types.
+ *
+ * The reference passes eleven raw device pointers per launch; here the scene arguments are
+ * bundled once into an opaque `pt_scene` (which re-packs them for gfx950) and the
+ * launchers take that handle. Errors: every entry point returns 0 on success or a negative
+ * code, never throws or exits (the reference's launchers return void and print,
+ * deviceCode.cu:611-619); pt_last_error() holds the message for the calling thread.
+ *
+ * `novum_*` entry points are the host side the reference keeps in main.cu/objects.cuh (config
+ * parser, OBJ reader, SAH BVH builder, material table, camera, finalise) restated in plain C++.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API_VERSION 1
+#define PT_TILE_DIM 8          /* one wave64 renders one 8x8-pixel tile */
+#define PT_TILE_PIXELS 64
+
+/* ---- PODs with the reference's layouts ------------------------------------------------- */
+typedef struct pt_float4 { float x, y, z, w; } __attribute__((aligned(16))) pt_float4;   /* CUDA float4 */
+typedef struct pt_float2 { float x, y; } __attribute__((aligned(8))) pt_float2;           /* CUDA float2 */
+
+/* objects.cuh:12-20 — 48 B. Leaf: left = right = -1, first/primCount index BVHindices.
+ * Internal: primCount = 0, first = -1. Root is node 0 (main.cu:133-233). */
+typedef struct pt_bvh_node {
+    pt_float4 aabbMIN, aabbMAX;
+    int32_t left, right, first, primCount;
+} pt_bvh_node;
+
+/* objects.cuh:159-172 — 80 B. lightInd = index into the light list or -51 (main.cu:1054-1056). */
+typedef struct pt_triangle {
+    int32_t aInd, bInd, cInd;
+    int32_t naInd, nbInd, ncInd;
+    int32_t uvaInd, uvbInd, uvcInd;
+    int32_t materialID;
+    pt_float4 emission;
+    int32_t lightInd, triInd;
+} pt_triangle;
+
+/* objects.cuh:605-638 — 176 B. `type` is MaterialType (objects.cuh:595-603). */
+typedef struct pt_material {
+    uint8_t hasTexture; int32_t startInd, width, height;
+    uint8_t hasTransMap; int32_t tstartInd, twidth, theight;
+    int32_t type;
+    pt_float4 albedo;
+    float roughness;
+    pt_float4 eta, k;
+    float ior, metallic, specular, transmission;
+    uint8_t isSpecular, boundary, thinWalled;
+    pt_float4 absorption;
+    int32_t priority;
+} pt_material;
+
+/* objects.cuh:199-219 — 112 B, passed by value to the reference's kernels. */
+typedef struct pt_camera {
+    pt_float4 cameraOrigin;
+    int32_t w, h;
+    float xRot, yRot, zRot;
+    float aperture, focalDist, fovScale;
+    float antiAliasJitterDist;
+    pt_float4 forward, right, up;
+} pt_camera;
+
+enum { PT_MAT_DIFFUSE = 0, PT_MAT_METAL = 1, PT_MAT_SMOOTHDIELECTRIC = 2, PT_MAT_MICROFACETDIELECTRIC = 3,
+       PT_MAT_LEAF = 4, PT_MAT_FLOWER = 5, PT_MAT_DELTAMIRROR = 6 };          /* objects.cuh:595-603 */
+enum { PT_UNIDIRECTIONAL = 0, PT_NAIVE_UNIDIRECTIONAL = 2 };                  /* objects.cuh:570-576 */
+
+/* What initRender uploads before the launch (main.cu:469-557), as HOST arrays. */
+typedef struct pt_scene_desc {
+    const pt_float4* positions; int32_t n_positions;       /* Vertices.positions */
+    const pt_float4* normals;   int32_t n_normals;         /* Vertices.normals   */
+    const pt_float2* uvs;       int32_t n_uvs;             /* Vertices.uvs       */
+    const pt_triangle* triangles; int32_t n_triangles;     /* `scene`            */
+    const pt_triangle* lights;    int32_t n_lights;        /* `lights` (copies of the emissive triangles) */
+    const pt_bvh_node* bvh;       int32_t n_nodes;         /* `BVH`              */
+    const int32_t* bvh_indices;                            /* `BVHindices`, n_triangles entries */
+    const pt_material* materials; int32_t n_materials;     /* `materials`        */
+    const pt_float4* textures;    int32_t n_texels;        /* `textures`         */
+} pt_scene_desc;
+
+typedef struct pt_scene pt_scene;      /* opaque: device-resident, re-packed scene */
+
+/* A rank's share of the framebuffer: tiles {first + i*stride : 0 <= i < count} of the row-major
+ * grid of ceil(w/8) x ceil(h/8) 8x8-pixel tiles. NULL means every tile. */
+typedef struct pt_tile_range { int32_t first, stride, count; } pt_tile_range;
+
+/* Work counters of SURVEY.md §8(d), summed over every render since pt_reset_counters. */
+typedef struct pt_counters {
+    uint64_t rays_closest, rays_shadow, node_pops, box_tests, tri_tests, hits, rng_draws, iterations;
+} pt_counters;
+
+/* ---- library ------------------------------------------------------------------------- */
+int pt_api_version(void);
+const char* pt_last_error(void);
+int pt_device_count(void);                 /* number of HIP devices, < 0 on error */
+
+/* ---- scene --------------------------------------------------------------------------- */
+/* Re-packs and uploads the scene to the CURRENT HIP device. NULL on error. Replaces the
+ * cudaMalloc/cudaMemcpy block main.cu:469-557. */
+pt_scene* pt_scene_create(const pt_scene_desc* desc);
+void pt_scene_destroy(pt_scene* scene);
+
+/* ---- launchers (the hot path) -------------------------------------------------------- */
+/* launch_unidirectional (integrator 0, useMIS as at main.cu:565) / launch_naive_unidirectional
+ * (integrator 2): seeds one XORWOW stream per pixel keyed by the GLOBAL index y*w+x
+ * (deviceCode.cu:59-60), runs `spp` samples per pixel with the stream continuing across
+ * samples, and ADDS the radiance sum into `out_rgba_sum` (w*h float4, row-major, y = 0 is the
+ * bottom row; `colors[pixelIdx] += Li`, deviceCode.cu:540). Host-buffer, blocking form. Only
+ * pixels of tiles in `tiles` are touched. */
+int pt_render(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
+              int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles, float* out_rgba_sum);
+
+/* Device-resident forms, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * d_tile_rgba: count*64 float4, tile-major ([local tile][ly*8+lx]); += semantics. */
+int pt_render_tiles_device(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
+                           int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles,
+                           void* d_tile_rgba, int count_work, void* stream);
+/* scan-line `colors` (w*h float4) <- tile-major buffer, for the tiles of `tiles`. */
+int pt_untile_device(int w, int h, const pt_tile_range* tiles, const void* d_tile_rgba, void* d_colors, void* stream);
+/* tile-major buffer <- scan-line `colors` (to continue an accumulation). */
+int pt_tile_device(int w, int h, const pt_tile_range* tiles, const void* d_colors, void* d_tile_rgba, void* stream);
+
+/* The reference's own call shape with the scene bundled (deviceCode.cuh:8-12): d_colors is the
+ * zero-initialised DEVICE accumulator of main.cu:337-339; blocking; seed 103033
+ * (deviceCode.cu:552); vertNum/triNum/lightNum live in the scene. */
+int pt_launch_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors);
+int pt_launch_naive_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors);
+
+/* Same as pt_render plus per-pixel counters (w*h x 8 uint32: rays_closest, rays_shadow,
+ * node_pops, box_tests, tri_tests, hits, rng_draws, iterations) for parity checks. */
+int pt_render_counted(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
+                      int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles,
+                      float* out_rgba_sum, uint32_t* out_counters);
+
+int pt_get_counters(pt_scene* scene, pt_counters* out);
+int pt_reset_counters(pt_scene* scene);
+/* Device time (ms) of the most recent megakernel launch on this scene, from HIP events recorded
+ * on the launch stream around that kernel alone; waits for the launch to finish. */
+float pt_last_kernel_ms(pt_scene* scene);
+
+/* ---- probes: single stages of the path on the GPU, for known-answer tests -------------- */
+int pt_probe_rng(uint64_t seed, int n, const uint32_t* subsequences, int n_draws, uint32_t* out_state6, uint32_t* out_u32, float* out_uniform);
+int pt_probe_math(int n, const float* x, float* out_sin, float* out_cos, float* out_exp, float* out_rsqrt, float* out_pow5);
+int pt_probe_camera_rays(const pt_camera* camera, uint64_t seed, int n, const int32_t* xy, float* out_rays6);
+/* rays: n x 6 floats. out_i: n x 4 (valid, triIDX, materialID, backface);
+ * out_f: n x 12 (t,u,v, point xyz, normal xyz, uv xy, 0); counters: summed over the n rays. */
+int pt_probe_trace_closest(pt_scene* scene, int n, const float* rays6, int32_t* out_i, float* out_f, pt_counters* counters);
+int pt_probe_trace_shadow(pt_scene* scene, int n, const float* rays6, const float* max_t, float* out_throughput3, pt_counters* counters);
+/* sample_f_eval on stream (seed, subseq): out 8 floats (wo xyz, f xyz, pdf, draws) */
+int pt_probe_bsdf_sample(pt_scene* scene, int n, const int32_t* material, const float* wi3, const int32_t* backface,
+                         float etaI, float etaT, uint64_t seed, const uint32_t* subseq, float* out8);
+/* f_eval + pdf_eval: out 4 floats (f xyz, pdf) */
+int pt_probe_bsdf_eval(pt_scene* scene, int n, const int32_t* material, const float* wi3, const float* wo3,
+                       float etaI, float etaT, float* out4);
+
+/* ---- novum_*: the kept host side (scene loader / initRender) --------------------------- */
+typedef struct novum_scene novum_scene;    /* host arrays + RenderConfig + Camera */
+
+/* loadConfig (objects.cuh:844-943) + material table (main.cu:397-467) + readObjSimple per mesh
+ * (main.cu:474-482, 936-1068) + computeInfoForBVH/buildBVH (main.cu:524-530) + camera
+ * (main.cu:268-273). Mesh paths are resolved against base_dir (NULL = directory of the config). */
+novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number);
+void novum_scene_free(novum_scene* s);
+/* info[16]: width,height,spp,maxDepth,integrator,leafSize,nTris,nLights,nNodes,nPoints,nNormals,
+ * nUvs,nMats,largestLeaf,backupCount,treeDepth */
+void novum_scene_info(const novum_scene* s, int32_t* info16);
+void novum_scene_desc(const novum_scene* s, pt_scene_desc* out);     /* pointers stay owned by s */
+void novum_scene_camera(const novum_scene* s, pt_camera* out);
+/* Camera::Pinhole / Camera::NotPinhole (objects.cuh:221-264) */
+void novum_make_camera(int pinhole, const float* pos3, const float* rot3, float fov, float aperture, float focal_dist, int w, int h, pt_camera* out);
+/* main.cu:860-870: colors /= spp; NaN -> (1,0,1); Inf -> (0,1,0). n = pixel count. */
+void novum_finalise(float* rgba, int n, int sample_count);
+/* initRender (main.cu:235-923) for the two unidirectional integrators: load, upload, launch,
+ * read back, finalise into out_rgba (w*h float4, may be NULL) and, if bmp_path != NULL, write the
+ * tonemapped 24-bit BMP (imageUtil.cu:69-100, 202-232). Returns 0, or < 0 on error. */
+int novum_init_render(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path);
+/* Image::saveImageBMP (imageUtil.cu:69-100): rgba is w*h float4 linear radiance, y = 0 bottom. */
+int novum_save_bmp(const char* path, const float* rgba, int w, int h, int post_process);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

@@ -1,0 +1,51 @@
+"""Shared fixtures. GPU tests are marked `gpu`; everything else runs on CPU.
+
+Only tests (and bench.py's cpu_baseline leg / smoke()) touch oracle/ — see oracle/README.md.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py as O
+    O.build()
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def api():
+    from cudapathtracer_amd import api as A
+    A.lib()
+    return A
+
+
+@pytest.fixture(scope="session")
+def scene_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("scenes"))
+
+
+def golden_scene(name):
+    return os.path.join(GOLDEN, "scenes", name + ".rendertron")
+
+
+@pytest.fixture(scope="session")
+def gpu_ready(api):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu test selected but no HIP device is visible")
+    torch.cuda.set_device(0)
+    return torch

@@ -1,0 +1,93 @@
+"""The product's scene loader (novum_*, plain C++) against the oracle's independent restatement of
+main.cu / objects.cuh, array for array, plus the parser quirks SURVEY.md §5 lists."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_scene
+
+ARRAYS = ["points", "normals", "uvs", "mesh", "lights", "bvh", "indices", "materials"]
+
+
+def _same(api, oracle, cfg, render_number=0):
+    hs = api.HostScene(cfg, render_number=render_number)
+    osc = oracle.OracleScene(cfg, render_number=render_number)
+    assert hs.info == osc.info
+    for k in ARRAYS:
+        a, b = hs.array(k), osc.array(k)
+        if k in ("points", "normals", "uvs"):
+            assert np.array_equal(a.view(np.float32), b.view(np.float32)), k      # -0.0 == 0.0
+        else:
+            assert np.array_equal(a, b), k
+    assert hs.camera().tobytes() == osc.camera().tobytes()
+    return hs
+
+
+@pytest.mark.parametrize("name", ["cornell32", "mixed32", "metal32"])
+def test_golden_scenes_load_identically(api, oracle, name):
+    _same(api, oracle, golden_scene(name))
+
+
+def test_blob_scene_and_tree_shape(api, oracle, scene_dir):
+    from cudapathtracer_amd import scenes
+    s = scenes.blob_in_box(os.path.join(scene_dir, "blob4"), 96, 54, 2, 8, subdiv=4, name="blob4")
+    hs = _same(api, oracle, s["config"])
+    i = hs.info
+    assert i["n_tris"] == 20 * 4 ** 4 + 12 and i["n_lights"] == 2 and i["leaf_size"] == 2
+    bvh = hs.array("bvh").view(np.int32).reshape(-1, 12)
+    left, right, first, count = bvh[:, 8], bvh[:, 9], bvh[:, 10], bvh[:, 11]
+    leaf = count > 0
+    assert np.all(left[leaf] == -1) and np.all(right[leaf] == -1)
+    assert np.all(first[~leaf] == -1) and np.all(left[~leaf] == np.flatnonzero(~leaf) + 1)     # pre-order: left child follows its parent
+    assert count[leaf].sum() == i["n_tris"] and sorted(hs.array("indices").view(np.int32)) == list(range(i["n_tris"]))
+
+
+def test_light_offset_by_render_number(api, oracle):
+    hs0 = _same(api, oracle, golden_scene("cornell32"), 0)
+    hs3 = _same(api, oracle, golden_scene("cornell32"), 3)
+    p0 = hs0.array("points").view(np.float32).reshape(-1, 4); p3 = hs3.array("points").view(np.float32).reshape(-1, 4)
+    moved = np.flatnonzero(np.any(p0 != p3, axis=1))
+    lights = hs0.array("lights").view(np.int32).reshape(-1, 20)
+    assert set(moved) == set(lights[:, :3].ravel())                       # only the emissive mesh moves (main.cu:476-478)
+    assert np.allclose(p3[moved, 1] - p0[moved, 1], -0.03, atol=1e-6)
+
+
+def test_parser_and_obj_quirks(api, oracle, tmp_path):
+    (tmp_path / "q.obj").write_text(
+        "# comment\ns off\n"
+        "v 0 0 -2\nv 1 0 -2\nv 1 1 -2\nv 0 1 -2\nv 2 0 -2\n"
+        "vt 0.25 0.75\n"
+        "vn 0 0 1\nvn 0 0 0\nvn nan 0 1\n"
+        "f 1/1/1 2/1/1 3/1/1 4/1/1\n"      # quad -> fan of two
+        "f 1 2 5\n"                         # degenerate (collinear): culled
+        "f 1//2 3//2 4//2\n"                # zero-length vn -> (0,1,0); no vt -> uv (0,0)
+        "f 2 3 5\n")                        # no vn: geometric normal synthesised
+    (tmp_path / "q.rendertron").write_text(
+        "Name: quirks\nwidth: 16\nheight: 8\nIntegrator: NAIVE_UNIDIRECTIONAL\nSample Count: 3\n"
+        "Unidirectional Max Depth: 5\nBVH recommended leaf size: 1\nBDPT Specifc Settings:\nVCM Initial Merge Radius Multipler: 0.01\n"
+        "Some Unknown Key: 12\nPinhole Camera: false\nCamera Position: 0.5 0.25 1.0\nCamera Rotation: 0 10 0\n"
+        "Camera Apeture: 0.0\nCamera FocalDist: 2.0\nCamera FOV: 45.0\n"
+        "Meshes (path; multiplier * emission; materialID):\nq.obj; 2.0 * (1.0, 0.5, 0.25); 6\n")
+    hs = _same(api, oracle, str(tmp_path / "q.rendertron"))
+    i = hs.info
+    assert (i["width"], i["height"], i["spp"], i["max_depth"], i["integrator"], i["leaf_size"]) == (16, 8, 3, 5, 2, 1)
+    assert i["n_tris"] == 4 and i["n_lights"] == 4
+    mesh = hs.array("mesh").view(np.int32).reshape(-1, 20)
+    assert np.all(mesh[:, 9] == 6) and list(mesh[:, 16]) == [0, 1, 2, 3] and list(mesh[:, 17]) == [0, 1, 2, 3]
+    em = hs.array("mesh").view(np.float32).reshape(-1, 20)[:, 12:15]
+    assert np.allclose(em, [2.0, 1.0, 0.5])
+    n = hs.array("normals").view(np.float32).reshape(-1, 4)
+    assert np.array_equal(n[1, :3], [0, 1, 0]) and np.array_equal(n[2, :3], [0, 1, 0])
+    assert np.allclose(np.abs(n[mesh[3, 3], :3]), [0, 0, 1])              # synthesised geometric normal
+    uv = hs.array("uvs").view(np.float32).reshape(-1, 2)
+    assert np.allclose(uv[0], [0.25, 0.25]) and np.array_equal(uv[mesh[2, 6]], [0, 0])      # v flipped: 1 - 0.75
+    cam = hs.camera()
+    assert cam.aperture == 0.0 and cam.focalDist == 2.0 and cam.w == 16 and cam.h == 8     # NotPinhole keeps aperture 0
+    ph = api.Camera.Pinhole((0, 0, 1), 32, 32)
+    assert abs(ph.aperture - 1e-6) < 1e-12 and abs(ph.focalDist - 1 / 60.0) < 1e-9          # objects.cuh:234-235
+
+
+def test_missing_files(api):
+    with pytest.raises(api.PtError):
+        api.HostScene("/nonexistent/x.rendertron")

@@ -1,0 +1,58 @@
+"""The oracle against the committed golden fixtures (regression pins; see make_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_scene
+from util import assert_bits_equal
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reproduces_golden(oracle, case):
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    sc = oracle.OracleScene(golden_scene(str(g["scene"])))
+    col, cnt, _ = sc.render(spp=int(g["spp"]), max_depth=int(g["max_depth"]), integrator=int(g["integrator"]),
+                            seed=int(g["seed"]), counters=True, threads=2)
+    assert_bits_equal(col, g["colors"], case)
+    assert np.array_equal(cnt, g["counters"])
+
+
+def test_region_and_thread_invariance(oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell32_mis.npz"))
+    sc = oracle.OracleScene(golden_scene("cornell32"))
+    col, _, _ = sc.render(integrator=0, rect=(8, 4, 24, 20), threads=3)
+    assert_bits_equal(col[4:20, 8:24], g["colors"][4:20, 8:24])
+    assert not col[:4].any() and not col[:, :8].any()
+
+
+def test_accumulates_into_existing_colors(oracle):
+    sc = oracle.OracleScene(golden_scene("cornell32"))
+    a, _, _ = sc.render(spp=2, integrator=0)
+    pre = np.full((32, 32, 4), 0.25, np.float32)
+    b, _, _ = sc.render(spp=2, integrator=0, colors=pre.copy())
+    # (0.25 + L0) + L1 in float32, per pixel, and w untouched
+    assert np.array_equal(b[..., 3], pre[..., 3])
+    assert np.allclose(b[..., :3], a[..., :3] + 0.25, rtol=1e-6, atol=1e-6)
+
+
+def test_naive_and_mis_converge(oracle, scene_dir):
+    """The reference's README (:70-92) argues both integrators estimate the same integral. With
+    the whole ceiling emitting (no reachable emitter back side) they must agree statistically."""
+    from cudapathtracer_amd import scenes
+    s = scenes.cornell(os.path.join(scene_dir, "cl"), 16, 16, 4, 4, ceiling_light=True, name="cl")
+    sc = oracle.OracleScene(s["config"])
+    a, _, _ = sc.render(spp=384, max_depth=40, integrator=0, threads=4)
+    b, _, _ = sc.render(spp=384, max_depth=40, integrator=2, threads=4)
+    ma, mb = a[..., :3].mean(axis=(0, 1)), b[..., :3].mean(axis=(0, 1))
+    assert np.all(np.abs(ma - mb) / ma < 0.02), (ma, mb)
+
+
+def test_finalise(oracle):
+    c = np.zeros((2, 2, 4), np.float32)
+    c[0, 0] = [4, 8, 12, 0]; c[0, 1] = [np.nan, 1, 1, 0]; c[1, 0] = [np.inf, 1, 1, 0]
+    f = oracle.finalise(c, 4).reshape(2, 2, 4)
+    assert np.array_equal(f[0, 0, :3], [1, 2, 3]) and np.array_equal(f[0, 1, :3], [1, 0, 1]) and np.array_equal(f[1, 0, :3], [0, 1, 0])
