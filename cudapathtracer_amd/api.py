@@ -218,6 +218,24 @@ class Scene:
             raise PtError("pt_scene_create failed: " + lib().pt_last_error().decode(errors="replace"))
 
     @staticmethod
+    def from_arrays(arrays):
+        """pt_scene_create straight from arrays in the reference's layouts (dict of buffers: points,
+        normals, uvs, mesh, lights, bvh, indices, materials[, textures])."""
+        a = {k: np.ascontiguousarray(v).view(np.uint8) for k, v in arrays.items()}
+        d = SceneDesc()
+        d.positions, d.n_positions = a["points"].ctypes.data, a["points"].size // 16
+        d.normals, d.n_normals = a["normals"].ctypes.data, a["normals"].size // 16
+        d.uvs, d.n_uvs = a["uvs"].ctypes.data, a["uvs"].size // 8
+        d.triangles, d.n_triangles = a["mesh"].ctypes.data, a["mesh"].size // 80
+        d.lights, d.n_lights = (a["lights"].ctypes.data if a["lights"].size else None), a["lights"].size // 80
+        d.bvh, d.n_nodes = a["bvh"].ctypes.data, a["bvh"].size // 48
+        d.bvh_indices = a["indices"].ctypes.data
+        d.materials, d.n_materials = a["materials"].ctypes.data, a["materials"].size // 176
+        t = a.get("textures")
+        d.textures, d.n_texels = (t.ctypes.data if t is not None and t.size else None), (t.size // 16 if t is not None else 0)
+        return Scene(desc=d)
+
+    @staticmethod
     def from_config(config_path, base_dir=None, render_number=0):
         hs = HostScene(config_path, base_dir, render_number)
         return Scene(hs), hs

@@ -25,6 +25,25 @@ void* oracle_scene_load(const char* configPath, const char* baseDir, int renderN
     return s;
 }
 
+// The scene straight from arrays in the reference's data model (what initRender uploads,
+// main.cu:469-557): lets tests hand-build trees the SAH builder would never produce.
+void* oracle_scene_from_arrays(const void* points, int nPoints, const void* normals, int nNormals, const void* uvs, int nUvs,
+                               const void* mesh, int nTris, const void* lights, int nLights, const void* bvh, int nNodes,
+                               const int* indices, const void* mats, int nMats) {
+    OracleScene* s = new OracleScene();
+    s->sc.points.assign((const float4*)points, (const float4*)points + nPoints);
+    s->sc.normals.assign((const float4*)normals, (const float4*)normals + nNormals);
+    s->sc.uvs.assign((const float2*)uvs, (const float2*)uvs + nUvs);
+    s->sc.mesh.assign((const Triangle*)mesh, (const Triangle*)mesh + nTris);
+    s->sc.lights.assign((const Triangle*)lights, (const Triangle*)lights + nLights);
+    s->sc.bvh.assign((const BVHnode*)bvh, (const BVHnode*)bvh + nNodes);
+    s->sc.indices.assign(indices, indices + nTris);
+    s->sc.mats.assign((const Material*)mats, (const Material*)mats + nMats);
+    s->cfg.integratorType = "UNIDIRECTIONAL";
+    s->cam = cameraPinhole(f4(0.0f, 0.0f, 1.0f), 8, 8, 0.0f, 0.0f, 0.0f, 60.0f);
+    return s;
+}
+
 void oracle_scene_free(void* h) { delete (OracleScene*)h; }
 
 // info[0..15]: width,height,spp,maxDepth,integrator,leafSize,nTris,nLights,nNodes,nPoints,

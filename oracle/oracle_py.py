@@ -37,6 +37,9 @@ def lib():
         L = C.CDLL(_SO)
         L.oracle_scene_load.restype = C.c_void_p
         L.oracle_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.oracle_scene_from_arrays.restype = C.c_void_p
+        L.oracle_scene_from_arrays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_scene_free.argtypes = [C.c_void_p]
         L.oracle_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_scene_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -68,11 +71,20 @@ def _p(a):
 class OracleScene:
     """The scene exactly as the reference's initRender assembles it (main.cu:235-557)."""
 
-    def __init__(self, config_path, base_dir=None, render_number=0):
-        base = base_dir if base_dir is not None else os.path.dirname(os.path.abspath(config_path))
-        self.h = lib().oracle_scene_load(config_path.encode(), base.encode(), render_number)
+    def __init__(self, config_path=None, base_dir=None, render_number=0, arrays=None):
+        if arrays is not None:
+            # arrays: dict of uint8 buffers in the reference's layouts (points, normals, uvs, mesh, lights, bvh, indices, materials)
+            a = {k: np.ascontiguousarray(v).view(np.uint8) for k, v in arrays.items()}
+            self._keep = a
+            self.h = lib().oracle_scene_from_arrays(_p(a["points"]), a["points"].size // 16, _p(a["normals"]), a["normals"].size // 16,
+                                                    _p(a["uvs"]), a["uvs"].size // 8, _p(a["mesh"]), a["mesh"].size // 80,
+                                                    _p(a["lights"]), a["lights"].size // 80, _p(a["bvh"]), a["bvh"].size // 48,
+                                                    _p(a["indices"]), _p(a["materials"]), a["materials"].size // 176)
+        else:
+            base = base_dir if base_dir is not None else os.path.dirname(os.path.abspath(config_path))
+            self.h = lib().oracle_scene_load(config_path.encode(), base.encode(), render_number)
         if not self.h:
-            raise RuntimeError("oracle: could not load " + config_path)
+            raise RuntimeError("oracle: could not load " + str(config_path))
         info = np.zeros(16, np.int32)
         lib().oracle_scene_info(self.h, _p(info))
         self.info = dict(zip(INFO_KEYS, (int(v) for v in info)))

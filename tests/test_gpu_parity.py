@@ -56,19 +56,50 @@ def _scene_pair(api, oracle, cfg):
     return api.Scene(hs), hs, oracle.OracleScene(cfg)
 
 
-def _deep_scene(scene_dir):
-    """Triangles at geometrically shrinking positions: SAH degenerates into a chain deeper than the
-    32-entry LDS stack, so the global spill path is exercised."""
-    from cudapathtracer_amd import scenes
-    m = scenes.Mesh("chain", 2)
-    x = 1.5
-    for k in range(60):
-        s = x * 0.18
-        m.quad((x - s, -s, -2.0 - 0.001 * k), (x + s, -s, -2.0 - 0.001 * k), (x + s, s, -2.0 - 0.001 * k), (x - s, s, -2.0 - 0.001 * k), (0, 0, 1))
-        x *= 0.72
-    light = scenes.Mesh("light", 2, 5.0, (1, 1, 1))
-    light.quad((-0.5, 0.9, -2.2), (0.5, 0.9, -2.2), (0.5, 0.9, -1.2), (-0.5, 0.9, -1.2), (0, -1, 0))
-    return scenes._emit(os.path.join(scene_dir, "deep"), "deep", [m, light], 24, 16, 4, 3, leaf=1)
+def _chain_arrays(api, n=50):
+    """Hand-built left-deep chain BVH over n triangles stacked along -z (array-level boundary, the
+    data model of main.cu:469-557): every internal node has the FARTHEST remaining triangle as its
+    leaf child, so a ray from +z descends n-1 internal nodes with one far child pending at each
+    level — deeper than the 32-entry LDS stack, which exercises the global spill path."""
+    hs = api.HostScene(golden_scene("cornell32"))
+    mats = hs.array("materials")
+    pts = np.zeros((3 * n + 3, 4), np.float32)
+    mesh = np.zeros((n + 1, 20), np.int32)
+    meshf = mesh.view(np.float32)
+    for k in range(n):
+        z = -1.0 - 0.05 * k
+        dx, dy = 0.03 * np.sin(k), 0.03 * np.cos(1.7 * k)
+        pts[3 * k:3 * k + 3, :3] = [(-1 + dx, -1 + dy, z), (1 + dx, -1 + dy, z), (dx, 1.2 + dy, z)]
+    pts[3 * n:3 * n + 3, :3] = [(-0.5, 2.0, -2.0), (0.5, 2.0, -2.0), (0.0, 2.0, -1.0)]        # one light triangle above
+    for k in range(n + 1):
+        mesh[k, 0:3] = [3 * k, 3 * k + 1, 3 * k + 2]
+        mesh[k, 3:6] = 1 if k == n else 0
+        mesh[k, 6:9] = 0
+        mesh[k, 9] = [2, 6, 23, 17][k % 4] if k < n else 2
+        mesh[k, 16], mesh[k, 17] = (0, k) if k == n else (-51, k)
+    meshf[n, 12:15] = [5.0, 5.0, 5.0]
+    normals = np.array([[0, 0, 1, 0], [0, -1, 0, 0]], np.float32)
+    uvs = np.zeros((1, 2), np.float32)
+    lo = pts[:, :3].reshape(-1, 3, 3).min(axis=1) - 1e-6
+    hi = pts[:, :3].reshape(-1, 3, 3).max(axis=1) + 1e-6
+    order = list(range(n + 1))                       # BVHindices: leaf i holds triangle order[i]
+    nodes = np.zeros((2 * (n + 1) - 1, 12), np.float32)
+    ni = nodes.view(np.int32)
+    # node 0 = root over everything; chain: internal node j (j = 0..n-1) has left = leaf of the farthest remaining tri
+    remaining = list(range(n + 1))                   # light (index n) is peeled first, then tri n-1, n-2, ...
+    idx = 0
+    for j in range(n):
+        far = remaining.pop()                        # farthest remaining
+        leaf_id, next_id = idx + 1, idx + 2
+        nodes[idx, 0:3] = np.minimum(lo[remaining + [far]].min(axis=0), lo[far]); nodes[idx, 4:7] = hi[remaining + [far]].max(axis=0)
+        ni[idx, 8:12] = [leaf_id, next_id, -1, 0]
+        nodes[leaf_id, 0:3] = lo[far]; nodes[leaf_id, 4:7] = hi[far]
+        ni[leaf_id, 8:12] = [-1, -1, far, 1]
+        idx = next_id
+    nodes[idx, 0:3] = lo[0]; nodes[idx, 4:7] = hi[0]
+    ni[idx, 8:12] = [-1, -1, 0, 1]
+    lights = mesh[n:n + 1].copy()
+    return dict(points=pts, normals=normals, uvs=uvs, mesh=mesh, lights=lights, bvh=nodes, indices=np.array(order, np.int32), materials=mats)
 
 
 @pytest.mark.parametrize("which", ["cornell32", "mixed32", "metal32", "blob3", "deep"])
@@ -77,15 +108,19 @@ def test_traversal_probes(api, oracle, gpu_ready, scene_dir, which):
     if which == "blob3":
         cfg = scenes.blob_in_box(os.path.join(scene_dir, "blob3g"), 64, 36, 1, 4, subdiv=3, name="blob3")["config"]
     elif which == "deep":
-        cfg = _deep_scene(scene_dir)["config"]
+        cfg = None
     else:
         cfg = golden_scene(which)
-    gs, hs, osc = _scene_pair(api, oracle, cfg)
     if which == "deep":
-        assert hs.info["tree_depth"] > 36, hs.info
+        arr = _chain_arrays(api)
+        gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
+    else:
+        gs, hs, osc = _scene_pair(api, oracle, cfg)
     rays = random_rays(np.random.default_rng(5), 8192)
     if which == "deep":
-        rays[:, :3] = [0.3, 0.0, 0.0]; rays[:, 3:] = np.array([0.0, 0.0, -1.0]) + 0.35 * (np.random.default_rng(6).random((8192, 3)) - 0.5)
+        rays[:, :3] = [0.0, 0.0, 1.0] + 0.2 * (np.random.default_rng(9).random((8192, 3)) - 0.5)
+        rays[:, 3:] = np.array([0.0, 0.0, -1.0]) + 0.5 * (np.random.default_rng(6).random((8192, 3)) - 0.5)
+        rays[::7, 3:] *= -1                          # some rays from behind / missing
     gi, gf, gc = gs.trace_closest(rays)
     oi, of, oc = osc.trace_closest(rays)
     assert np.array_equal(gi, oi)
@@ -140,7 +175,6 @@ def test_render_matches_golden(api, gpu_ready, case):
 def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integrator):
     from cudapathtracer_amd import scenes
     cfgs = [scenes.blob_in_box(os.path.join(scene_dir, "blob3r"), 45, 27, 3, 6, subdiv=3, name="blob3r")["config"],      # ragged size
-            _deep_scene(scene_dir)["config"],
             scenes.cornell(os.path.join(scene_dir, "cl2"), 24, 24, 6, 12, ceiling_light=True, tall_material=18, short_material=8, nested=True, name="cl2")["config"]]
     for cfg in cfgs:
         gs, hs, osc = _scene_pair(api, oracle, cfg)
@@ -149,6 +183,19 @@ def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integr
         ocol, ocnt, _ = osc.render(integrator=integrator, counters=True, threads=8)
         assert np.array_equal(cnt, ocnt), cfg
         assert_bits_equal(col, ocol, cfg)
+
+
+@pytest.mark.parametrize("integrator", [0, 2])
+def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator):
+    """Array-level boundary + a tree deeper than the LDS stack, through the full render loop."""
+    arr = _chain_arrays(api)
+    gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
+    cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
+    col, cnt = gs.render(cam, 24, 16, 4, 5, integrator=integrator, counters=True)
+    ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=24, height=16, spp=4, max_depth=5, integrator=integrator, counters=True)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col, ocol, "deep chain render")
+    assert cnt[..., 5].sum() > 100
 
 
 def test_tile_ranges_and_accumulation(api, gpu_ready):
