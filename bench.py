@@ -45,22 +45,45 @@ def alg_bytes(c, n_px):
     return 32 * c["box_tests"] + 16 * c["node_pops"] + 52 * c["tri_tests"] + 96 * c["hits"] + 16 * n_px
 
 
-def cpu_baseline(cfg, info, seconds_budget=20.0):
+def host_threads():
+    """Threads the CPU baseline may use: the cgroup CPU quota if one is set (a 1-GPU box is given a
+    16-CPU share of a larger host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("PT_BENCH_CPU_THREADS", "16")))
+
+
+def cpu_baseline(cfg, info, seconds_budget=15.0):
     """The oracle (kind "port": this repo's CPU restatement; the CUDA reference cannot be built here)
     on a bounded sample of the workload: the full frame at a reduced sample count."""
     from oracle import oracle_py as O          # checker / reported baseline only
-    cores = len(os.sched_getaffinity(0))
+    cores = host_threads()
     sc = O.OracleScene(cfg)
     w, h = info["width"], info["height"]
-    # calibrate on a strided band, then size spp for ~seconds_budget
-    col, cnt, secs = sc.render(spp=1, rect=(0, h // 2, w, h // 2 + 16), counters=True, threads=cores)
-    per_spp = secs * (h / 16.0)
-    spp = int(max(1, min(8, seconds_budget / max(per_spp, 1e-3))))
+    _, _, t1 = sc.render(spp=1, threads=cores)                       # calibrate: whole frame, 1 spp
+    spp = int(max(1, min(64, seconds_budget / max(t1, 1e-3))))
     col, cnt, secs = sc.render(spp=spp, counters=True, threads=cores)
     rays = int(cnt[..., 0].sum() + cnt[..., 1].sum())
     return {"value": rays / secs / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
             "msample_per_s": w * h * spp / secs / 1e6,
-            "sample": "full 1920x1080 frame at %d of %d spp (%.1f s), same scene/seed/depth, all host threads" % (spp, info["spp"], secs)}
+            "sample": "full %dx%d frame at %d of %d spp (%.1f s), same scene/seed/depth, %d host threads" % (w, h, spp, info["spp"], secs, cores)}
+
+
+def pmc_traffic(workload, spp):
+    """HBM bytes per megakernel launch from the committed rocprofv3 PMC passes (profiles/), if they
+    were taken on this workload; None otherwise. bench.py cannot run the profiler on itself."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if t.get("workload") == workload and t.get("spp") == spp:
+            return t["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -163,7 +186,7 @@ def main():
                        "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": "interleaved 8x8 tiles, 1 gather" if world > 1 else "none",
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pt::megakernel<0,false>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
+                         "traffic": pmc_traffic(args.workload, spp) if world == 1 else None, "kernel": "pt::megakernel<0,false>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sinfo["config"], info)
