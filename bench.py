@@ -105,10 +105,18 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # PT_BENCH_SHARE_GPU=1 is a REHEARSAL mode for a 1-GPU box: every rank uses cuda:0 and the gather
+    # goes through gloo; the JSON says so. The real N > 1 run is one GPU per rank over RCCL.
+    share = os.environ.get("PT_BENCH_SHARE_GPU") == "1"
+    dev = 0 if share else local_rank
+    torch.cuda.set_device(dev)
+    red_dev = "cpu" if share else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     from cudapathtracer_amd import api, scenes
     from cudapathtracer_amd import distributed as D
@@ -146,7 +154,7 @@ def main():
     step(count_work=True)
     fence()
     cnt = scene.counters()
-    cvec = torch.tensor([cnt[k] for k in api.COUNTER_KEYS], dtype=torch.float64, device="cuda")
+    cvec = torch.tensor([cnt[k] for k in api.COUNTER_KEYS], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(cvec)
     total = dict(zip(api.COUNTER_KEYS, (int(v) for v in cvec.tolist())))
@@ -158,13 +166,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
-            pass
     fence()
     elapsed = time.perf_counter() - t0
     # per-launch megakernel time from HIP events on its stream (last launch; all launches are identical)
     kernel_ms = scene.last_kernel_ms()
-    et = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+    et = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = et.tolist()
@@ -183,7 +189,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp,
                        "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "seed": api.SEED,
-                       "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": "interleaved 8x8 tiles, 1 gather" if world > 1 else "none",
+                       "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, spp) if world == 1 else None, "kernel": "pt::megakernel<0,false>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},

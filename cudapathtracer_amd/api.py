@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libptamd.so")
+# PT_LIB_PATH selects another BUILD of the same HIP library (kernel A/B variants); it is never a fallback.
+LIB_PATH = os.environ.get("PT_LIB_PATH") or os.path.join(_HERE, "csrc", "libptamd.so")
 
 UNIDIRECTIONAL = 0
 NAIVE_UNIDIRECTIONAL = 2
@@ -100,6 +101,7 @@ def lib():
     L.pt_get_counters.argtypes = [vp, vp]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
+    L.pt_debug_stamps.argtypes = [vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.pt_probe_camera_rays.argtypes = [C.POINTER(Camera), u64, i32, vp, vp]
@@ -282,6 +284,11 @@ class Scene:
 
     def reset_counters(self):
         _check(lib().pt_reset_counters(self.h), "pt_reset_counters")
+
+    def debug_stamps(self):
+        out = np.zeros(6, np.uint64)
+        _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
+        return dict(zip(("regen", "closest", "shade_pre", "shadow", "shade_post", "loop"), (int(v) for v in out)))
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

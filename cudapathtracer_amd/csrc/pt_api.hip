@@ -56,7 +56,7 @@ struct pt_scene {
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
     DevBuf rng, spill, tilebuf, colors, pixcnt;       // work buffers, grown on demand
     DeviceScene ds{};
-    int stackNeed = 0, nInternal = 0;
+    int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     float lastKernelMs = 0.0f;
     bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -97,7 +97,8 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         return fail(-1, "pt_scene_create: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
     if (d->n_materials <= 0 || d->n_materials > 256) return fail(-1, "pt_scene_create: %d materials (1..256 supported)", d->n_materials);
 
-    // --- internal nodes in the reference's (pre-order) numbering, compacted ---
+    // --- internal nodes renumbered BREADTH-FIRST from the root, so PNodes [0, K) are the top of the
+    //     tree (the part every ray visits) and can be staged in LDS as one contiguous block ---
     std::vector<int> internalId(nN, -1);
     int nInternal = 0;
     for (int i = 0; i < nN; i++) {
@@ -106,7 +107,19 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
             if (n.first < 0 || n.first + n.primCount > nT) return fail(-1, "pt_scene_create: leaf %d range [%d,+%d) out of bounds", i, n.first, n.primCount);
         } else {
             if (n.left < 0 || n.right < 0 || n.left >= nN || n.right >= nN) return fail(-1, "pt_scene_create: internal node %d has child out of range", i);
-            internalId[i] = nInternal++;
+        }
+    }
+    {
+        std::vector<int> queue;
+        if (d->bvh[0].primCount <= 0) { queue.push_back(0); internalId[0] = nInternal++; }
+        for (size_t q = 0; q < queue.size(); q++) {
+            const pt_bvh_node& n = d->bvh[queue[q]];
+            for (int c : {n.left, n.right}) {
+                if (d->bvh[c].primCount > 0) continue;
+                if (internalId[c] >= 0 || (int)queue.size() >= nN) return fail(-1, "pt_scene_create: BVH is not a tree");
+                internalId[c] = nInternal++;
+                queue.push_back(c);
+            }
         }
     }
     auto childRef = [&](int c) -> int32_t { return d->bvh[c].primCount > 0 ? ~d->bvh[c].first : internalId[c]; };
@@ -115,6 +128,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     for (int i = 0; i < nN; i++) {
         const pt_bvh_node& n = d->bvh[i];
         if (n.primCount > 0) { leafEnd[n.first + n.primCount - 1] = 1; continue; }
+        if (internalId[i] < 0) continue;                       // unreachable from the root
         PNode& p = nodes[internalId[i]];
         const pt_bvh_node& L = d->bvh[n.left];
         const pt_bvh_node& R = d->bvh[n.right];
@@ -222,8 +236,8 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     if (int r = upload(s->textures, d->textures, (size_t)std::max(d->n_texels, 0) * sizeof(float4))) return r;
     const std::vector<uint32_t>& jt = xorwow_host::jump_table();
     if (int r = upload(s->jump, jt.data(), jt.size() * sizeof(uint32_t))) return r;
-    if (int r = s->totals.ensure(8 * sizeof(unsigned long long))) return r;
-    HIP_OK(hipMemset(s->totals.p, 0, 8 * sizeof(unsigned long long)));
+    if (int r = s->totals.ensure(16 * sizeof(unsigned long long))) return r;      // 8 counters + 6 diagnostic stamp sums
+    HIP_OK(hipMemset(s->totals.p, 0, 16 * sizeof(unsigned long long)));
 
     s->nInternal = nInternal;
     s->stackNeed = stackNeed;
@@ -232,13 +246,20 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     s->ds.rootRef = childRef(0);
     s->ds.nLights = d->n_lights; s->ds.nTris = nT;
     s->ds.stackSpill = std::max(0, stackNeed - kStackLds);
+    // scene cache: everything if it fits the LDS budget, else only the top of the (breadth-first) tree
+    if ((size_t)nInternal * 64 + (size_t)nT * 48 <= (size_t)kCacheBytes) { s->cacheNodes = nInternal; s->cacheTris = nT; }
+    else { s->cacheNodes = std::min(nInternal, kCacheBytes / 64); s->cacheTris = 0; }
     return 0;
 }
 
 pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     if (!desc) { fail(-1, "pt_scene_create: null desc"); return nullptr; }
     pt_scene* s = new pt_scene();
-    if (hipGetDevice(&s->device) != hipSuccess) { fail(-2, "pt_scene_create: no HIP device (the path has no CPU fallback)"); delete s; return nullptr; }
+    if (hipError_t e = hipGetDevice(&s->device); e != hipSuccess) {
+        fail(-2, "pt_scene_create: no usable HIP device (%s); the path has no CPU fallback", hipGetErrorString(e));
+        delete s;
+        return nullptr;
+    }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { fail(-2, "hipEventCreate failed"); pt_scene_destroy(s); return nullptr; }
     return s;
@@ -292,6 +313,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cam = cam_to_kernel(*cam);
     P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
+    P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;
@@ -389,9 +411,16 @@ int pt_get_counters(pt_scene* s, pt_counters* out) {
 }
 int pt_reset_counters(pt_scene* s) {
     if (!s) return fail(-1, "null scene");
-    HIP_OK(hipMemset(s->totals.p, 0, sizeof(pt_counters)));
+    HIP_OK(hipMemset(s->totals.p, 0, 16 * sizeof(unsigned long long)));
     return 0;
 }
+// Diagnostic builds (-DPT_STAMPS) only: the six per-phase s_memtime sums; zeros otherwise.
+int pt_debug_stamps(pt_scene* s, unsigned long long* out6) {
+    if (!s || !out6) return fail(-1, "null argument");
+    HIP_OK(hipMemcpy(out6, (unsigned long long*)s->totals.p + 8, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 float pt_last_kernel_ms(pt_scene* s) {
     if (!s) return -1.0f;
     if (s->evPending) {                                // waits for the last megakernel launch to finish

@@ -83,7 +83,8 @@ PT_DEV void resolve_hit(const DeviceScene& S, const Hit& h, V3 o, V3 d, HitInfo&
 }
 
 // removeMaterialFromStack, integratorUtilities.cuh:414-434 (entry 0 is never removed)
-PT_DEV void medium_remove(uint8_t* ms, int& top, int materialID) {
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+PT_DEV void medium_remove(lds_u8_t* ms, int& top, int materialID) {
     int found = -1;
     for (int i = top - 1; i > 0; i--) if (ms[i * 64] == materialID) { found = i; break; }
     if (found != -1) {
@@ -92,23 +93,56 @@ PT_DEV void medium_remove(uint8_t* ms, int& top, int materialID) {
     }
 }
 
+// Dynamic LDS of one workgroup: [scene cache: nodes | tris][4 traversal stacks][4 medium stacks].
+extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
+
+// All threads of the workgroup copy the cached part of the scene into LDS (16 B per thread per step).
+PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int cacheTris) {
+    typedef __attribute__((address_space(3))) f4v lds_f4;
+    lds_f4* dstN = (lds_f4*)pt_smem;
+    lds_f4* dstT = dstN + cacheNodes * 4;
+    const f4v* srcN = reinterpret_cast<const f4v*>(S.nodes);
+    const f4v* srcT = reinterpret_cast<const f4v*>(S.tris);
+    for (int i = threadIdx.x; i < cacheNodes * 4; i += blockDim.x) dstN[i] = srcN[i];
+    for (int i = threadIdx.x; i < cacheTris * 3; i += blockDim.x) dstT[i] = srcT[i];
+    __syncthreads();
+    SceneCache C;
+    C.nodes = (lds_cf4*)dstN; C.nNodes = cacheNodes;
+    C.tris = (lds_cf4*)dstT; C.nTris = cacheTris;
+    return C;
+}
+
+// Diagnostic build only (-DPT_STAMPS): wave-level s_memtime shares per phase, summed into
+// totals[8..13] (regen, closest traversal, shade-before-shadow, shadow traversal, shade-after, loop
+// overhead). Never quote this build's run time (cdna_hip_programming.md §7, In-kernel stamps).
+#ifdef PT_STAMPS
+#define PT_STAMP(slot) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp[slot] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define PT_STAMP(slot) do {} while (0)
+#endif
+
 template <int INTEG, bool COUNT>
-__global__ void __launch_bounds__(256) megakernel(KParams P) {
-    __shared__ int32_t ldsStack[4][kStackLds][64];
-    __shared__ uint8_t ldsMedium[4][kMediumMax][64];
+__global__ void __launch_bounds__(256)
+#if PT_MIN_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
+#endif
+megakernel(KParams P) {
+    const DeviceScene& S = P.S;
+    const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lt = blockIdx.x * 4 + wave;
     if (lt >= P.tileCount) return;
-    const DeviceScene& S = P.S;
     const int tile = P.tileFirst + lt * P.tileStride;
     const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
     const bool inImage = (x < P.w) && (y < P.h);
 
+    const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
     Stack<kStackLds> st;
-    st.lds = &ldsStack[wave][0][lane];
+    st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (kStackLds * 64) + lane;
     st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
     st.sp = 0;
-    uint8_t* ms = &ldsMedium[wave][0][lane];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    lds_u8* ms = (lds_u8*)(pt_smem + cacheBytes + 4 * kStackLds * 256) + wave * (kMediumMax * 64) + lane;
 
     Rng rng;
     {
@@ -128,7 +162,12 @@ __global__ void __launch_bounds__(256) megakernel(KParams P) {
     bool hitFirstNonSpecular = false;
     const int depthLimit = (INTEG == 2) ? P.maxDepth : 100;
 
+#ifdef PT_STAMPS
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
+        PT_STAMP(5);
         if (!inPath && samplesLeft > 0) {
             samplesLeft--;
             inPath = true;
@@ -138,6 +177,7 @@ __global__ void __launch_bounds__(256) megakernel(KParams P) {
             depth = 0; guard = 0; msTop = 1; ms[0] = 0;
             hitFirstNonSpecular = false;
         }
+        PT_STAMP(0);
         if (__ballot(inPath) == 0ull) break;
         if (!inPath) continue;
 
@@ -147,7 +187,9 @@ __global__ void __launch_bounds__(256) megakernel(KParams P) {
         if (!done) {
             if (COUNT) c.iters++;
             Hit h;
-            trace_closest<COUNT, kStackLds>(S, o, d, 999999.0f, st, h, c);
+            PT_STAMP(5);
+            trace_closest<COUNT, kStackLds>(S, SC, o, d, 999999.0f, st, h, c);
+            PT_STAMP(1);
             if (h.tri < 0) {
                 Li = Li + beta * v3(0.0f);             // `Li += beta * sampleSky()`; the sky is black (integratorUtilities.cuh:436-438)
                 done = true;
@@ -253,7 +295,9 @@ __global__ void __launch_bounds__(256) megakernel(KParams P) {
                                     float tt, uu, vv;
                                     if (moller_trumbore(A, B - A, C - A, ro, wi, tt, uu, vv)) t = tt;
                                 }
-                                V3 thr = trace_shadow<COUNT, kStackLds>(S, ro, wi, t * (1.0f - kEps), st, c);
+                                PT_STAMP(2);
+                                V3 thr = trace_shadow<COUNT, kStackLds>(S, SC, ro, wi, t * (1.0f - kEps), st, c);
+                                PT_STAMP(3);
                                 if (dot(thr, thr) > 0.0f) {
                                     float dist2 = dot(s2l, s2l);
                                     float cosL = dot(ld3(L.na), -wi);
@@ -304,12 +348,16 @@ __global__ void __launch_bounds__(256) megakernel(KParams P) {
                 }
             }
         }
+        PT_STAMP(4);
         if (done) {
             acc = acc + Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
             inPath = false;
         }
     }
 
+#ifdef PT_STAMPS
+    if (P.totals && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
+#endif
     if (inImage) P.out[(size_t)lt * 64 + lane] = make_float4(acc.x, acc.y, acc.z, acc4.w);
     {
         uint32_t* r = P.rng + (size_t)lt * 384 + lane;
@@ -396,13 +444,14 @@ __global__ void __launch_bounds__(64) probe_closest_kernel(DeviceScene S, int n,
                                                            unsigned long long* totals, int32_t* spill) {
     __shared__ int32_t ldsStack[kStackLds][64];
     int i = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
-    Stack<kStackLds> st; st.lds = &ldsStack[0][lane]; st.sp = 0;
+    Stack<kStackLds> st; st.lds = (lds_i32*)&ldsStack[0][0] + lane; st.sp = 0;
+    SceneCache C; C.nodes = nullptr; C.nNodes = 0; C.tris = nullptr; C.nTris = 0;
     st.spill = spill ? spill + ((size_t)blockIdx.x * S.stackSpill) * 64 + lane : nullptr;
     Ctr c = {};
     if (i < n) {
         V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
         Hit h;
-        trace_closest<true, kStackLds>(S, o, d, 999999.0f, st, h, c);
+        trace_closest<true, kStackLds>(S, C, o, d, 999999.0f, st, h, c);
         float* f = outF + 12 * i;
         for (int k = 0; k < 12; k++) f[k] = 0.0f;
         if (h.tri >= 0) {
@@ -420,12 +469,13 @@ __global__ void __launch_bounds__(64) probe_shadow_kernel(DeviceScene S, int n, 
                                                           unsigned long long* totals, int32_t* spill) {
     __shared__ int32_t ldsStack[kStackLds][64];
     int i = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
-    Stack<kStackLds> st; st.lds = &ldsStack[0][lane]; st.sp = 0;
+    Stack<kStackLds> st; st.lds = (lds_i32*)&ldsStack[0][0] + lane; st.sp = 0;
+    SceneCache C; C.nodes = nullptr; C.nNodes = 0; C.tris = nullptr; C.nTris = 0;
     st.spill = spill ? spill + ((size_t)blockIdx.x * S.stackSpill) * 64 + lane : nullptr;
     Ctr c = {};
     if (i < n) {
         V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-        V3 t = trace_shadow<true, kStackLds>(S, o, d, maxT[i], st, c);
+        V3 t = trace_shadow<true, kStackLds>(S, C, o, d, maxT[i], st, c);
         outF[3 * i] = t.x; outF[3 * i + 1] = t.y; outF[3 * i + 2] = t.z;
     }
     wave_add_total(totals, 0, c.raysClosest); wave_add_total(totals, 1, c.raysShadow); wave_add_total(totals, 2, c.pops);
@@ -469,12 +519,13 @@ hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w,
 hipError_t launch_megakernel(int integrator, bool count, const KParams& P, hipStream_t stream) {
     if (P.tileCount <= 0) return hipSuccess;
     dim3 grid(megakernel_blocks(P.tileCount)), block(256);
+    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
     if (integrator == 2) {
-        if (count) hipLaunchKernelGGL((megakernel<2, true>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((megakernel<2, false>), grid, block, 0, stream, P);
+        if (count) hipLaunchKernelGGL((megakernel<2, true>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((megakernel<2, false>), grid, block, lds, stream, P);
     } else {
-        if (count) hipLaunchKernelGGL((megakernel<0, true>), grid, block, 0, stream, P);
-        else hipLaunchKernelGGL((megakernel<0, false>), grid, block, 0, stream, P);
+        if (count) hipLaunchKernelGGL((megakernel<0, true>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((megakernel<0, false>), grid, block, lds, stream, P);
     }
     return hipGetLastError();
 }

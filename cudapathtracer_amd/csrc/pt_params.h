@@ -5,14 +5,26 @@
 
 namespace pt {
 
-constexpr int kStackLds = 32;     // LDS traversal-stack entries per lane (8 KiB per wave)
+// Build-time knobs (A/B-able with -D...):
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 16           // LDS traversal-stack entries per lane (256 B each per wave); deeper trees spill to global
+#endif
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4            // amdgpu_waves_per_eu for the megakernel: caps VGPRs at 128 (0 = unconstrained)
+#endif
+#ifndef PT_CACHE_BYTES
+#define PT_CACHE_BYTES 12288      // LDS bytes per workgroup for the scene cache (top PNodes / all PTris)
+#endif
+constexpr int kStackLds = PT_STACK_LDS;
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
+constexpr int kCacheBytes = PT_CACHE_BYTES;
 
 struct KParams {
     DeviceScene S;
     CamK cam;
     int w, h, spp, maxDepth, useMIS;
     int tileFirst, tileStride, tileCount, tilesX;
+    int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
     uint32_t* rng;                 // [tile][6][64]
     float4* out;                   // [tile][64], += semantics
     uint32_t* pixCounters;         // [tile][8][64] or null
@@ -42,5 +54,8 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
 // waves a probe_closest/shadow launch of n rays uses (spill sizing)
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
 inline int megakernel_blocks(int tileCount) { return (tileCount + 3) / 4; }
+inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris) {
+    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)kStackLds * 256 + 4 * (size_t)kMediumMax * 64;
+}
 
 }  // namespace pt

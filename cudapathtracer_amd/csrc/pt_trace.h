@@ -12,7 +12,10 @@
 //   * the nearer child is kept in a register instead of being pushed and popped again (the
 //     reference pushes far then near and immediately pops near, :161-173; same order);
 //   * hit attributes are interpolated once, for the final hit (the reference does it on
-//     every improving hit, :113-141; same value, it is a pure function of the winner).
+//     every improving hit, :113-141; same value, it is a pure function of the winner);
+//   * the top of the tree (PNodes are numbered breadth-first) and, for small scenes, all packed
+//     triangles are staged once per workgroup in LDS (SceneCache): those fetches become
+//     ds_read_b128 instead of L1/L2 round trips.
 // Visiting order, tie rules (`tminL < tminR` else right first; strict `t < min_t`) and the
 // per-ray counters are exactly the reference's.
 #pragma once
@@ -22,13 +25,28 @@ namespace pt {
 
 struct Ctr { uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters; };
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+// Bit views of a float BY VALUE. (__builtin_bit_cast applied directly to an ext_vector element
+// lvalue, e.g. bit_cast<int>(v.y), reads element 0 with this compiler — always go through these.)
+PT_DEV int32_t f2i(float f) { return __builtin_bit_cast(int32_t, f); }
+PT_DEV uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+typedef __attribute__((address_space(3))) const f4v lds_cf4;
+
+// Workgroup-shared LDS copy of the first `nNodes` PNodes (4 x 16 B each) and, if the whole scene
+// fits, of all `nTris` PTris (3 x 16 B each). nTris is all-or-nothing so a leaf never straddles.
+struct SceneCache {
+    lds_cf4* nodes; int nNodes;
+    lds_cf4* tris; int nTris;
+};
+
 // Per-lane traversal stack: N entries in LDS (lane-interleaved: entry k of lane l lives at
 // word k*64 + l, so every access is bank-conflict-free), overflow in a global spill area with
 // the same interleave. The host sizes the spill from the tree depth; Cornell-class trees never
-// reach it.
+// reach it. The LDS pointer carries its address space so pops compile to ds_read, not flat loads.
 template <int N>
 struct Stack {
-    int32_t* lds;
+    lds_i32* lds;
     int32_t* spill;
     int sp;
     PT_DEV void push(int32_t v) {
@@ -37,7 +55,9 @@ struct Stack {
     }
     PT_DEV int32_t pop() {
         sp--;
-        return sp < N ? lds[sp * 64] : spill[(sp - N) * 64];
+        int32_t v;
+        if (sp < N) v = lds[sp * 64]; else v = spill[(sp - N) * 64];
+        return v;
     }
 };
 
@@ -72,21 +92,40 @@ PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u,
     return ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f)) && t > 0.0f;
 }
 
-struct NodeData { float4 a, b, c, d; };
-PT_DEV NodeData load_node(const PNode* nodes, int32_t i) {
-    const float4* p = reinterpret_cast<const float4*>(nodes + i);
-    return NodeData{p[0], p[1], p[2], p[3]};
+struct NodeData { f4v a, b, c, d; };
+PT_DEV NodeData load_node(const DeviceScene& S, const SceneCache& C, int32_t i) {
+    NodeData n;
+    if (i < C.nNodes) {
+        lds_cf4* p = C.nodes + i * 4;
+        n.a = p[0]; n.b = p[1]; n.c = p[2]; n.d = p[3];
+    } else {
+        const f4v* p = reinterpret_cast<const f4v*>(S.nodes + i);
+        n.a = p[0]; n.b = p[1]; n.c = p[2]; n.d = p[3];
+    }
+    return n;
+}
+struct TriData { f4v a, b, e; };
+PT_DEV TriData load_tri(const DeviceScene& S, const SceneCache& C, int32_t i) {
+    TriData t;
+    if (C.nTris) {                         // wave-uniform
+        lds_cf4* p = C.tris + i * 3;
+        t.a = p[0]; t.b = p[1]; t.e = p[2];
+    } else {
+        const f4v* p = reinterpret_cast<const f4v*>(S.tris + i);
+        t.a = p[0]; t.b = p[1]; t.e = p[2];
+    }
+    return t;
 }
 
 // One internal-node step shared by both traversals: returns the next ref to visit.
 template <bool COUNT, int N>
-PT_DEV int32_t descend(const DeviceScene& S, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c) {
-    NodeData n = load_node(S.nodes, cur);
+PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c) {
+    NodeData n = load_node(S, C, cur);
     if (COUNT) { c.pops++; c.boxes += 2; }
     float tL, tR;
     bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
     bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);
-    int32_t left = __builtin_bit_cast(int32_t, n.d.x), right = __builtin_bit_cast(int32_t, n.d.y);
+    int32_t left = f2i(n.d.x), right = f2i(n.d.y);
     if (hL && hR) {
         bool leftNear = tL < tR;
         st.push(leftNear ? right : left);
@@ -99,7 +138,7 @@ PT_DEV int32_t descend(const DeviceScene& S, int32_t cur, V3 o, V3 inv, Stack<N>
 
 // BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
 template <bool COUNT, int N>
-PT_DEV void trace_closest(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
+PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float min_t = 3.402823466e+38f;
     hit.tri = -1;
@@ -107,25 +146,24 @@ PT_DEV void trace_closest(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N
     int32_t cur = S.rootRef;
     if (COUNT) c.raysClosest++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N>(S, cur, o, inv, st, c);
+        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
         if (cur == kRefNone) break;
         if (COUNT) c.pops++;
-        const PTri* tp = S.tris + (~cur);
+        int32_t ti = ~cur;
         uint32_t idx;
         do {
-            const float4* q = reinterpret_cast<const float4*>(tp);
-            float4 a = q[0], b = q[1], e = q[2];
-            idx = __builtin_bit_cast(uint32_t, e.y);
+            TriData q = load_tri(S, C, ti);
+            idx = f2u(q.e.y);
             if (COUNT) c.tris++;
             float t, u, v;
-            bool ok = moller_trumbore(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, e.x), o, d, t, u, v);
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < min_t) && (t < max_t)) {
                 min_t = t;
                 hit.t = t; hit.u = u; hit.v = v;
                 hit.tri = (int32_t)(idx & 0x7fffffffu);
-                hit.material = __builtin_bit_cast(int32_t, e.z);
+                hit.material = f2i(q.e.z);
             }
-            tp++;
+            ti++;
         } while (!(idx & 0x80000000u));
         cur = st.sp > 0 ? st.pop() : kRefNone;
     }
@@ -141,30 +179,29 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 // BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
 template <bool COUNT, int N>
-PT_DEV V3 trace_shadow(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
+PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 thr = v3(1.0f);
     st.sp = 0;
     int32_t cur = S.rootRef;
     if (COUNT) c.raysShadow++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N>(S, cur, o, inv, st, c);
+        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
         if (cur == kRefNone) break;
         if (COUNT) c.pops++;
-        const PTri* tp = S.tris + (~cur);
+        int32_t ti = ~cur;
         uint32_t idx;
         do {
-            const float4* q = reinterpret_cast<const float4*>(tp);
-            float4 a = q[0], b = q[1], e = q[2];
-            idx = __builtin_bit_cast(uint32_t, e.y);
+            TriData q = load_tri(S, C, ti);
+            idx = f2u(q.e.y);
             if (COUNT) c.tris++;
             float t, u, v;
-            bool ok = moller_trumbore(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, e.x), o, d, t, u, v);
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < max_t)) {
-                uint32_t flags = __builtin_bit_cast(uint32_t, e.w);
+                uint32_t flags = f2u(q.e.w);
                 if (!(flags & 1u)) return v3(0.0f);
                 // MAT_LEAF (integratorUtilities.cuh:218-239)
-                const PMat& m = S.mats[__builtin_bit_cast(int32_t, e.z)];
+                const PMat& m = S.mats[f2i(q.e.z)];
                 const PAttr& at = S.attrs[idx & 0x7fffffffu];
                 float bz = 1.0f - u - v;
                 V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
@@ -174,7 +211,7 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, V3 o, V3 d, float max_t, Stack<N>& 
                 thr = thr * s;
                 if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) return v3(0.0f);
             }
-            tp++;
+            ti++;
         } while (!(idx & 0x80000000u));
         cur = st.sp > 0 ? st.pop() : kRefNone;
     }

@@ -47,6 +47,12 @@ def gather_tiles(local_tiles, w, h, rank, world, group=None):
 
     if world == 1:
         return [local_tiles]
+    if local_tiles.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal on a shared GPU / CPU tests: gloo gathers host tensors
+        host = local_tiles.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, gather_list=bufs, dst=0, group=group)
+        return [b.to(local_tiles.device) for b in bufs] if rank == 0 else None
     bufs = [torch.empty_like(local_tiles) for _ in range(world)] if rank == 0 else None
     dist.gather(local_tiles, gather_list=bufs, dst=0, group=group)
     return bufs

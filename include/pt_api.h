@@ -150,6 +150,10 @@ int pt_reset_counters(pt_scene* scene);
 /* Device time (ms) of the most recent megakernel launch on this scene, from HIP events recorded
  * on the launch stream around that kernel alone; waits for the launch to finish. */
 float pt_last_kernel_ms(pt_scene* scene);
+/* Diagnostic builds (-DPT_STAMPS) only: per-phase s_memtime sums of the megakernel since the last
+ * pt_reset_counters: regen, closest traversal, shading before the shadow ray, shadow traversal,
+ * shading after it, loop overhead. Zeros in a normal build. */
+int pt_debug_stamps(pt_scene* scene, unsigned long long* out6);
 
 /* ---- probes: single stages of the path on the GPU, for known-answer tests -------------- */
 int pt_probe_rng(uint64_t seed, int n, const uint32_t* subsequences, int n_draws, uint32_t* out_state6, uint32_t* out_u32, float* out_uniform);
