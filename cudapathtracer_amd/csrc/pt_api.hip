@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -57,6 +58,8 @@ struct pt_scene {
     DevBuf rng, spill, tilebuf, colors, pixcnt;       // work buffers, grown on demand
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
+    bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
+    bool deferShadow = false;    // PT_DEFER_SHADOW=1: megakernel traces shadow + extension ray as a pair (A/B; slower)
     float lastKernelMs = 0.0f;
     bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -176,6 +179,10 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         p.idx = (uint32_t)idx | (leafEnd[i] ? 0x80000000u : 0u);
         p.material = t.materialID;
         p.flags = d->materials[t.materialID].type == PT_MAT_LEAF ? 1u : 0u;
+        {
+            const int ty = d->materials[t.materialID].type;
+            if (!(ty == PT_MAT_DIFFUSE || ty == PT_MAT_METAL || ty == PT_MAT_SMOOTHDIELECTRIC || ty == PT_MAT_LEAF || ty == PT_MAT_DELTAMIRROR)) s->armless = true;
+        }
     }
     // --- hit attributes by original index ---
     std::vector<PAttr> attrs(nT);
@@ -261,6 +268,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
         return nullptr;
     }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
+    if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { fail(-2, "hipEventCreate failed"); pt_scene_destroy(s); return nullptr; }
     return s;
 }
@@ -319,7 +327,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;
     (void)timeIt;
     HIP_OK(hipEventRecord(s->ev0, stream));            // HIP events on the launch stream, around the megakernel only
-    HIP_OK(launch_megakernel(integrator, count, P, stream));
+    HIP_OK(launch_megakernel(integrator, count, !(s->deferShadow && !s->armless), P, stream));
     HIP_OK(hipEventRecord(s->ev1, stream));
     s->evPending = true;
     return 0;

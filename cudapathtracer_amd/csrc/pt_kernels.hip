@@ -15,7 +15,7 @@
 // ended starts its pixel's next sample at the top of the next bounce iteration, so the wave
 // keeps 64 live rays for traversal until the pixels run out of samples; the wave leaves the loop
 // when a ballot finds no live lane.
-#include "pt_shade.h"
+#include "pt_path.h"
 #include "pt_params.h"
 
 namespace pt {
@@ -62,37 +62,6 @@ __global__ void __launch_bounds__(256) rng_init_kernel(const uint32_t* __restric
     o[0] = v[0]; o[64] = v[1]; o[128] = v[2]; o[192] = v[3]; o[256] = v[4]; o[320] = d;
 }
 
-// -------------------------------------------------------------------------------------------
-struct HitInfo { V3 point, normal, emission; float uvx, uvy, dist; int tri, material, lightInd; bool backface; };
-
-// The attribute block of BVHSceneIntersect (integratorUtilities.cuh:113-141) for the final hit.
-PT_DEV void resolve_hit(const DeviceScene& S, const Hit& h, V3 o, V3 d, HitInfo& hi) {
-    const PAttr& at = S.attrs[h.tri];
-    float bz = 1.0f - h.u - h.v;
-    hi.point = v3(__builtin_fmaf(h.t, d.x, o.x), __builtin_fmaf(h.t, d.y, o.y), __builtin_fmaf(h.t, d.z, o.z));
-    V3 n = normalize(ld3(at.n0) * bz + ld3(at.n1) * h.u + ld3(at.n2) * h.v);
-    hi.uvx = at.uv0[0] * bz + at.uv1[0] * h.u + at.uv2[0] * h.v;
-    hi.uvy = at.uv0[1] * bz + at.uv1[1] * h.u + at.uv2[1] * h.v;
-    if (dot(n, d) > 0.0f) { n = -n; hi.backface = true; } else hi.backface = false;
-    hi.normal = n;
-    hi.material = at.material;
-    hi.emission = ld3(at.emission);
-    hi.lightInd = at.lightInd;
-    hi.tri = h.tri;
-    hi.dist = h.t;
-}
-
-// removeMaterialFromStack, integratorUtilities.cuh:414-434 (entry 0 is never removed)
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
-PT_DEV void medium_remove(lds_u8_t* ms, int& top, int materialID) {
-    int found = -1;
-    for (int i = top - 1; i > 0; i--) if (ms[i * 64] == materialID) { found = i; break; }
-    if (found != -1) {
-        for (int i = found; i < top - 1; i++) ms[i * 64] = ms[(i + 1) * 64];
-        top--;
-    }
-}
-
 // Dynamic LDS of one workgroup: [scene cache: nodes | tris][4 traversal stacks][4 medium stacks].
 extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
 
@@ -112,16 +81,22 @@ PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int ca
     return C;
 }
 
-// Diagnostic build only (-DPT_STAMPS): wave-level s_memtime shares per phase, summed into
-// totals[8..13] (regen, closest traversal, shade-before-shadow, shadow traversal, shade-after, loop
-// overhead). Never quote this build's run time (cdna_hip_programming.md §7, In-kernel stamps).
+// Diagnostic build only (-DPT_STAMPS): wave-level s_memtime shares, summed into totals[8..9]
+// (logic step, traversal). Never quote this build's run time (cdna_hip_programming.md §7).
 #ifdef PT_STAMPS
 #define PT_STAMP(slot) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp[slot] += now_ - tprev; tprev = now_; } while (0)
 #else
 #define PT_STAMP(slot) do {} while (0)
 #endif
 
-template <int INTEG, bool COUNT>
+PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
+    if (defer && (ps.flags & kShadowPending)) { ps.LiFinish = ps.Li; ps.flags |= kFinishPending; }   // last NEE term still in flight
+    else acc = acc + ps.Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
+    ps.flags &= ~kInPath;
+}
+
+// INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h.
+template <int INTEG, bool COUNT, bool DEFER>
 __global__ void __launch_bounds__(256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
@@ -141,227 +116,61 @@ megakernel(KParams P) {
     st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (kStackLds * 64) + lane;
     st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
     st.sp = 0;
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    lds_u8* ms = (lds_u8*)(pt_smem + cacheBytes + 4 * kStackLds * 256) + wave * (kMediumMax * 64) + lane;
+    LdsMedium ms;
+    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + 4 * kStackLds * 256) + wave * (kMediumMax * 64) + lane;
 
-    Rng rng;
+    PathState ps;
     {
         const uint32_t* r = P.rng + (size_t)lt * 384 + lane;
-        rng.v0 = r[0]; rng.v1 = r[64]; rng.v2 = r[128]; rng.v3 = r[192]; rng.v4 = r[256]; rng.d = r[320];
+        ps.rng.v0 = r[0]; ps.rng.v1 = r[64]; ps.rng.v2 = r[128]; ps.rng.v3 = r[192]; ps.rng.v4 = r[256]; ps.rng.d = r[320];
     }
+    ps.o = v3(0.0f); ps.d = v3(0.0f); ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
+    ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps; ps.depth = 0; ps.guard = 0; ps.msTop = 1; ps.flags = 0;
+    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; ps.LiFinish = v3(0.0f);
     float4 acc4 = P.out[(size_t)lt * 64 + lane];
     V3 acc = v3(acc4.x, acc4.y, acc4.z);
     Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
-
     int samplesLeft = inImage ? P.spp : 0;
-    bool inPath = false;
-    // path state
-    V3 o = v3(0.0f), d = v3(0.0f), beta = v3(1.0f), Li = v3(0.0f), prevPoint = v3(0.0f), woLocal = v3(0.0f);
-    float pdf = kEps, etaI = kEps, etaT = kEps;
-    int depth = 0, guard = 0, msTop = 1;
-    bool hitFirstNonSpecular = false;
-    const int depthLimit = (INTEG == 2) ? P.maxDepth : 100;
+    Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+    V3 thr = v3(1.0f);
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, kStackLds>(S, SC, ro, wi, maxt, st, c); };
 
 #ifdef PT_STAMPS
-    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp[2] = {0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
+    // Every iteration: one logic step per lane (finish the previous bounce's NEE, shade the hit,
+    // regenerate if the path ended), then one traversal round for the rays the logic produced. A
+    // lane whose path ended starts its pixel's next sample in the same step, so the wave keeps 64
+    // live rays until the pixels run out of samples; a ballot ends the wave.
     while (true) {
-        PT_STAMP(5);
-        if (!inPath && samplesLeft > 0) {
+        if (DEFER) apply_pending(ps, thr, acc);
+        if (ps.flags & kInPath) {
+            bool done = path_bounce<INTEG, COUNT, DEFER>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+            if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
+            if (done) path_finish(ps, acc, DEFER);
+        }
+        while (!(ps.flags & kInPath) && samplesLeft > 0) {
             samplesLeft--;
-            inPath = true;
-            camera_ray<COUNT>(P.cam, rng, x, y, o, d, c);
-            beta = v3(1.0f); Li = v3(0.0f); prevPoint = v3(0.0f); woLocal = v3(0.0f);
-            pdf = kEps; etaI = kEps; etaT = kEps;
-            depth = 0; guard = 0; msTop = 1; ms[0] = 0;
-            hitFirstNonSpecular = false;
+            path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+            if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, DEFER);
         }
+        const bool hasExt = (ps.flags & kInPath) != 0;
+        const bool hasShadow = DEFER && (ps.flags & kShadowPending) != 0;
         PT_STAMP(0);
-        if (__ballot(inPath) == 0ull) break;
-        if (!inPath) continue;
-
-        bool done = false;
-        if (depth >= depthLimit) done = true;
-        else if (INTEG != 2 && ++guard > 4096) done = true;
-        if (!done) {
-            if (COUNT) c.iters++;
-            Hit h;
-            PT_STAMP(5);
-            trace_closest<COUNT, kStackLds>(S, SC, o, d, 999999.0f, st, h, c);
-            PT_STAMP(1);
-            if (h.tri < 0) {
-                Li = Li + beta * v3(0.0f);             // `Li += beta * sampleSky()`; the sky is black (integratorUtilities.cuh:436-438)
-                done = true;
-            } else {
-                HitInfo hi;
-                resolve_hit(S, h, o, d, hi);
-                const PMat& m = S.mats[hi.material];
-                if (INTEG == 2) {
-                    // ---- Li_naive_unidirectional, deviceCode.cu:172-202 ----
-                    V3 toSurface = to_local(d, hi.normal);
-                    V3 f = v3(0.0f), toNext = v3(0.0f);
-                    float p = 0.0f;
-                    sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
-                    if (p <= 0.0f || dot(f, f) < kEps) done = true;
-                    else {
-                        Li = Li + hi.emission * beta;
-                        beta = beta * ((f * __builtin_fabsf(toNext.z)) / p);
-                        V3 nw = to_world(toNext, hi.normal);
-                        o = hi.point + ((toNext.z > 0.0f) ? (hi.normal * kRayEps) : ((-hi.normal) * kRayEps));
-                        d = nw;
-                        depth++;
-                    }
-                } else {
-                    // ---- Li_unidirectional, deviceCode.cu:332-537 ----
-                    V3 wiLocal = to_local(d, hi.normal);
-                    bool isSpecular = (m.flags & kMatSpecular) != 0;
-                    bool trueHit = true;
-                    int minPrior = S.mats[ms[0]].priority, minPriorID = ms[0];
-                    for (int i = 1; i < msTop; i++) {
-                        int id = ms[i * 64];
-                        int pr = S.mats[id].priority;
-                        if (pr < minPrior) { minPrior = pr; minPriorID = id; }
-                    }
-                    const PMat& dom = S.mats[minPriorID];
-                    if (hi.dist > kEps) {
-                        V3 att = v3(exp_(-dom.absorption[0] * hi.dist), exp_(-dom.absorption[1] * hi.dist), exp_(-dom.absorption[2] * hi.dist));
-                        beta = beta * att;
-                    }
-                    if (m.flags & kMatBoundary) {
-                        if (m.priority <= minPrior) {
-                            if (m.type == 2) {
-                                etaI = dom.ior;
-                                if (!hi.backface) etaT = m.ior;
-                                else if (msTop == 1) etaT = 1.0f;
-                                else {
-                                    int mp = 99, second = ms[0];
-                                    for (int i = 0; i < msTop; i++) {
-                                        int id = ms[i * 64];
-                                        int pr = S.mats[id].priority;
-                                        if (pr) { if (mp > pr && id != hi.material) { second = id; mp = pr; } }
-                                    }
-                                    etaT = S.mats[second].ior;
-                                }
-                            }
-                        } else {
-                            trueHit = false;
-                            if (!hi.backface) { if (msTop < kMediumMax) { ms[msTop * 64] = (uint8_t)hi.material; msTop++; } }
-                            else medium_remove(ms, msTop, hi.material);
-                        }
-                    } else etaI = dom.ior;
-
-                    if (trueHit) {
-                        float le2 = dot(hi.emission, hi.emission);
-                        if (le2 > kEps) {
-                            if (depth == 0 || !hitFirstNonSpecular) Li = Li + beta * hi.emission;
-                            else if (P.useMIS && !isSpecular) {
-                                // neePDF, deviceCode.cu:63-85: the hit triangle as a light
-                                float lightPdf = kEps;
-                                if (hi.lightInd >= 0) {
-                                    const PLight& L = S.lights[hi.lightInd];
-                                    V3 s2l = hi.point - prevPoint;
-                                    V3 wi = normalize(s2l);
-                                    float dist2 = dot(s2l, s2l);
-                                    float cosL = dot(ld3(L.na), -wi);
-                                    float area = 0.5f * length(cross(ld3(L.b) - ld3(L.a), ld3(L.c) - ld3(L.a)));
-                                    lightPdf = dist2 / (cosL * (float)S.nLights * area);
-                                }
-                                if (lightPdf > kEps) {
-                                    float wB = pdf * pdf / (lightPdf * lightPdf + pdf * pdf);
-                                    Li = Li + (beta * hi.emission) * wB;
-                                }
-                            }
-                        }
-                        if (P.useMIS && le2 < kEps && !isSpecular) {
-                            // nextEventEstimation, deviceCode.cu:87-156
-                            float lightPdf = kEps;
-                            V3 nee = v3(0.0f);
-                            if (S.nLights == 0) lightPdf = -1.0f;
-                            else {
-                                int index = min((int)(draw<COUNT>(rng, c) * (float)S.nLights), S.nLights - 1);
-                                const PLight& L = S.lights[index];
-                                V3 A = ld3(L.a), B = ld3(L.b), C = ld3(L.c);
-                                float u = __builtin_sqrtf(draw<COUNT>(rng, c));
-                                float v = draw<COUNT>(rng, c);
-                                V3 p = (1.0f - u) * A + (u * (1.0f - v)) * B + (u * v) * C;
-                                V3 s2l = p - hi.point;
-                                V3 wi = normalize(s2l);
-                                V3 ro = hi.point + wi * kEps;
-                                // t to the light triangle; if that test fails the reference leaves t
-                                // uninitialised (:121-123) — defined as |s2l| - EPSILON
-                                float t = length(s2l) - kEps;
-                                {
-                                    float tt, uu, vv;
-                                    if (moller_trumbore(A, B - A, C - A, ro, wi, tt, uu, vv)) t = tt;
-                                }
-                                PT_STAMP(2);
-                                V3 thr = trace_shadow<COUNT, kStackLds>(S, SC, ro, wi, t * (1.0f - kEps), st, c);
-                                PT_STAMP(3);
-                                if (dot(thr, thr) > 0.0f) {
-                                    float dist2 = dot(s2l, s2l);
-                                    float cosL = dot(ld3(L.na), -wi);
-                                    float cosS = __builtin_fabsf(dot(hi.normal, wi));
-                                    float area = 0.5f * length(cross(B - A, C - A));
-                                    lightPdf = dist2 / (cosL * (float)S.nLights * area);
-                                    V3 wiL = to_local(wi, hi.normal);
-                                    woLocal = wiL;
-                                    V3 f = f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
-                                    nee = ((f * ld3(L.emission)) * cosS) / lightPdf;
-                                    nee = nee * thr;
-                                }
-                            }
-                            if (lightPdf > kEps) {
-                                pdf_eval(m, S.textures, wiLocal, woLocal, etaI, hi.uvx, hi.uvy, pdf);
-                                float wN = lightPdf * lightPdf / (pdf * pdf + lightPdf * lightPdf);
-                                Li = Li + (beta * nee) * wN;
-                            }
-                        }
-                        V3 f = v3(0.0f);
-                        sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
-                        V3 woWorld = to_world(woLocal, hi.normal);
-                        pdf = fmaxf_(pdf, 0.01f);
-                        if (woLocal.z < 0.0f) {
-                            if (!hi.backface) { if (msTop < kMediumMax) { ms[msTop * 64] = (uint8_t)hi.material; msTop++; } }
-                            else medium_remove(ms, msTop, hi.material);
-                        }
-                        beta = beta * ((f * __builtin_fabsf(woLocal.z)) / pdf);
-                        if (woLocal.z > 0.0f) o = hi.point + hi.normal * kEps;
-                        else o = hi.point - hi.normal * kEps;
-                        d = normalize(woWorld);
-                        prevPoint = hi.point;
-                    } else {
-                        woLocal = to_local(d, hi.normal);
-                        o = hi.point + d * kRayEps;
-                        depth--;
-                    }
-                    if (depth > P.maxDepth) {
-                        float lum = dot(beta, v3(0.2126f, 0.7152f, 0.0722f));
-                        float p = clampf(lum, 0.05f, 0.99f);
-                        if (draw<COUNT>(rng, c) > p) done = true;
-                        else beta = beta / p;
-                    }
-                    if (!done) {
-                        if (!isSpecular) hitFirstNonSpecular = true;
-                        depth++;
-                    }
-                }
-            }
-        }
-        PT_STAMP(4);
-        if (done) {
-            acc = acc + Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
-            inPath = false;
-        }
+        if (__ballot(hasExt || hasShadow) == 0ull) break;
+        if (DEFER) trace_pair<COUNT, kStackLds>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+        else if (hasExt) trace_closest<COUNT, kStackLds>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
+        PT_STAMP(1);
     }
 
 #ifdef PT_STAMPS
-    if (P.totals && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
+    if (P.totals && lane == 0) for (int k = 0; k < 2; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
 #endif
     if (inImage) P.out[(size_t)lt * 64 + lane] = make_float4(acc.x, acc.y, acc.z, acc4.w);
     {
         uint32_t* r = P.rng + (size_t)lt * 384 + lane;
-        r[0] = rng.v0; r[64] = rng.v1; r[128] = rng.v2; r[192] = rng.v3; r[256] = rng.v4; r[320] = rng.d;
+        r[0] = ps.rng.v0; r[64] = ps.rng.v1; r[128] = ps.rng.v2; r[192] = ps.rng.v3; r[256] = ps.rng.v4; r[320] = ps.rng.d;
     }
     if (COUNT) {
         if (P.pixCounters) {
@@ -516,16 +325,19 @@ hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w,
     return hipGetLastError();
 }
 
-hipError_t launch_megakernel(int integrator, bool count, const KParams& P, hipStream_t stream) {
+hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const KParams& P, hipStream_t stream) {
     if (P.tileCount <= 0) return hipSuccess;
     dim3 grid(megakernel_blocks(P.tileCount)), block(256);
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
     if (integrator == 2) {
-        if (count) hipLaunchKernelGGL((megakernel<2, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((megakernel<2, false>), grid, block, lds, stream, P);
+        if (count) hipLaunchKernelGGL((megakernel<2, true, false>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((megakernel<2, false, false>), grid, block, lds, stream, P);
+    } else if (syncShadow) {
+        if (count) hipLaunchKernelGGL((megakernel<0, true, false>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((megakernel<0, false, false>), grid, block, lds, stream, P);
     } else {
-        if (count) hipLaunchKernelGGL((megakernel<0, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((megakernel<0, false>), grid, block, lds, stream, P);
+        if (count) hipLaunchKernelGGL((megakernel<0, true, true>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((megakernel<0, false, true>), grid, block, lds, stream, P);
     }
     return hipGetLastError();
 }

@@ -36,7 +36,8 @@ struct TileSpan { int first, stride, count, tilesX; };
 
 // Launchers (asynchronous on `stream`); defined in pt_kernels.hip.
 hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w, int h, TileSpan t, uint32_t* rng, hipStream_t stream);
-hipError_t launch_megakernel(int integrator, bool count, const KParams& P, hipStream_t stream);
+// syncShadow: trace the NEE shadow ray inside the bounce (needed only for materials without a dispatch arm)
+hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const KParams& P, hipStream_t stream);
 hipError_t launch_untile(int w, int h, TileSpan t, const float4* tiles, float4* colors, hipStream_t stream);
 hipError_t launch_tile(int w, int h, TileSpan t, const float4* colors, float4* tiles, hipStream_t stream);
 hipError_t launch_probe_rng(const uint32_t* jump, unsigned long long seed, int n, const uint32_t* subseq, int nDraws,

@@ -218,4 +218,142 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
     return thr;
 }
 
+
+// ---- unified per-lane traverser -------------------------------------------------------------
+// The same two traversals as above as ONE resumable state machine, so that a lane can run its
+// rays back to back inside a single loop: the megakernel traces a bounce's shadow ray and the next
+// extension ray as a pair (the wave re-converges once per pair instead of once per ray), and the
+// wavefront kernel refills finished lanes from a ray queue. Visiting order, tests and counters per
+// ray are identical to trace_closest / trace_shadow.
+template <int N>
+struct Trav {
+    V3 o, d, inv;
+    float max_t, min_t;
+    int32_t cur;
+    bool shadow;
+    Hit hit;
+    V3 thr;
+
+    template <bool COUNT>
+    PT_DEV void start(const DeviceScene& S, Stack<N>& st, V3 o_, V3 d_, float maxt, bool shadow_, Ctr& c) {
+        o = o_; d = d_;
+        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        max_t = maxt; min_t = 3.402823466e+38f;
+        cur = S.rootRef; shadow = shadow_;
+        hit.tri = -1; hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f; hit.material = 0;
+        thr = v3(1.0f);
+        st.sp = 0;
+        if (COUNT) { if (shadow_) c.raysShadow++; else c.raysClosest++; }
+    }
+
+    // Descend to the next leaf and test its triangles. Returns true when the ray is finished.
+    template <bool COUNT>
+    PT_DEV bool step(const DeviceScene& S, const SceneCache& C, Stack<N>& st, Ctr& c) {
+        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+        if (cur == kRefNone) return true;
+        if (COUNT) c.pops++;
+        int32_t ti = ~cur;
+        uint32_t idx;
+        do {
+            TriData q = load_tri(S, C, ti);
+            idx = f2u(q.e.y);
+            if (COUNT) c.tris++;
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (shadow) {
+                if (ok && (t < max_t)) {
+                    uint32_t flags = f2u(q.e.w);
+                    if (!(flags & 1u)) { thr = v3(0.0f); cur = kRefNone; return true; }
+                    // MAT_LEAF (integratorUtilities.cuh:218-239)
+                    const PMat& m = S.mats[f2i(q.e.z)];
+                    const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                    float bz = 1.0f - u - v;
+                    V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                    float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                    float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                    V3 sc = ld3(m.albedo) * m.transmission * (1.0f - F);
+                    thr = thr * sc;
+                    if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); cur = kRefNone; return true; }
+                }
+            } else if (ok && (t < min_t) && (t < max_t)) {
+                min_t = t;
+                hit.t = t; hit.u = u; hit.v = v;
+                hit.tri = (int32_t)(idx & 0x7fffffffu);
+                hit.material = f2i(q.e.z);
+            }
+            ti++;
+        } while (!(idx & 0x80000000u));
+        cur = st.sp > 0 ? st.pop() : kRefNone;
+        return cur == kRefNone;
+    }
+};
+
+// Shadow ray (optional) then extension ray (optional) of one lane in a single loop. Both
+// reciprocal directions are computed up front (convergent code); a lane that finishes its shadow
+// ray switches to its extension ray with a handful of register moves and stays in the loop, so the
+// wave re-converges once per PAIR of rays.
+template <bool COUNT, int N>
+PT_DEV void trace_pair(const DeviceScene& S, const SceneCache& C, Stack<N>& st, bool hasShadow, V3 so, V3 sd, float smaxt,
+                       bool hasExt, V3 eo, V3 ed, V3& thr, Hit& h, Ctr& c) {
+    h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+    thr = v3(1.0f);
+    if (!hasShadow && !hasExt) return;
+    const V3 invS = v3(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
+    const V3 invE = v3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
+    if (COUNT) { if (hasShadow) c.raysShadow++; if (hasExt) c.raysClosest++; }
+    bool isShadow = hasShadow;
+    V3 o = isShadow ? so : eo, d = isShadow ? sd : ed, inv = isShadow ? invS : invE;
+    float max_t = isShadow ? smaxt : 999999.0f;
+    float min_t = 3.402823466e+38f;
+    int32_t cur = S.rootRef;
+    st.sp = 0;
+    while (true) {
+        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+        if (cur == kRefNone) {
+            if (isShadow && hasExt) {                 // shadow ray done: start this lane's extension ray
+                isShadow = false;
+                o = eo; d = ed; inv = invE; max_t = 999999.0f;
+                cur = S.rootRef; st.sp = 0;
+                continue;
+            }
+            break;
+        }
+        if (COUNT) c.pops++;
+        int32_t ti = ~cur;
+        uint32_t idx;
+        bool occluded = false;
+        do {
+            TriData q = load_tri(S, C, ti);
+            idx = f2u(q.e.y);
+            if (COUNT) c.tris++;
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (isShadow) {
+                if (ok && (t < max_t)) {
+                    uint32_t flags = f2u(q.e.w);
+                    if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                    // MAT_LEAF (integratorUtilities.cuh:218-239)
+                    const PMat& m = S.mats[f2i(q.e.z)];
+                    const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                    float bz = 1.0f - u - v;
+                    V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                    float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                    float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                    V3 sc = ld3(m.albedo) * m.transmission * (1.0f - F);
+                    thr = thr * sc;
+                    if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); occluded = true; break; }
+                }
+            } else if (ok && (t < min_t) && (t < max_t)) {
+                min_t = t;
+                h.t = t; h.u = u; h.v = v;
+                h.tri = (int32_t)(idx & 0x7fffffffu);
+                h.material = f2i(q.e.z);
+            }
+            ti++;
+        } while (!(idx & 0x80000000u));
+        cur = (!occluded && st.sp > 0) ? st.pop() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
+    }
+    if (COUNT) { if (hasExt && h.tri >= 0) c.hits++; }
+}
+
 }  // namespace pt

@@ -15,8 +15,11 @@ a = ap.parse_args()
 res = {n: [] for n in a.names}
 for r in range(a.rounds):
     for n in a.names:
-        lib = os.path.join(ROOT, "cudapathtracer_amd", "csrc", "variants", "lib_%s.so" % n)
+        base, _, opt = n.partition("+")              # "v3+defer" = lib_v3.so with PT_DEFER_SHADOW=1
+        lib = os.path.join(ROOT, "cudapathtracer_amd", "csrc", "variants", "lib_%s.so" % base)
         env = dict(os.environ, PT_LIB_PATH=lib)
+        if opt == "defer":
+            env["PT_DEFER_SHADOW"] = "1"
         if a.golden and r == 0:
             t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k", "golden or fresh or deep"], cwd=ROOT, env=env, capture_output=True, text=True)
             print(n, "parity:", t.stdout.strip().splitlines()[-1] if t.stdout.strip() else t.stderr[-300:], flush=True)
