@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--workload", default="cornell_1920x1080_1024spp_depth8_mis", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (diagnostics only; the JSON then says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="megakernel", choices=["megakernel", "wavefront"],
+                    help="kernel organisation (SURVEY §8 f-1 A/B); the headline is the megakernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +131,7 @@ def main():
     w, h, md = info["width"], info["height"], info["max_depth"]
     spp = args.spp or info["spp"]
     cam = host.camera()
-    scene = api.Scene(host)                                     # scene resident in HBM from here on
+    scene = api.Scene(host).set_variant(args.variant)           # scene resident in HBM from here on
 
     tr = api.rank_tiles(w, h, rank, world)
     pad = D.padded_tile_count(w, h, world)
@@ -188,11 +190,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp,
-                       "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "seed": api.SEED,
+                       "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "variant": args.variant, "seed": api.SEED,
                        "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, spp) if world == 1 else None, "kernel": "pt::megakernel<0,false>", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
+                         "traffic": pmc_traffic(args.workload, spp) if (world == 1 and args.variant == "megakernel") else None,
+                         "kernel": "pt::megakernel<0,false,false>" if args.variant == "megakernel" else "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sinfo["config"], info)

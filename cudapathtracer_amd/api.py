@@ -98,6 +98,7 @@ def lib():
     L.pt_tile_device.argtypes = [i32, i32, C.POINTER(TileRange), vp, vp, vp]
     L.pt_launch_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
     L.pt_launch_naive_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
+    L.pt_set_variant.argtypes = [vp, i32]
     L.pt_get_counters.argtypes = [vp, vp]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
@@ -276,6 +277,12 @@ class Scene:
 
     def launch_naive_unidirectional(self, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr):
         _check(lib().pt_launch_naive_unidirectional(max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr), "pt_launch_naive_unidirectional")
+
+    def set_variant(self, variant):
+        """0 / "megakernel" (default) or 1 / "wavefront" (stream-compacted A/B variant; same results)."""
+        v = {"megakernel": 0, "wavefront": 1}.get(variant, variant)
+        _check(lib().pt_set_variant(self.h, int(v)), "pt_set_variant")
+        return self
 
     def counters(self):
         out = np.zeros(8, np.uint64)

@@ -56,6 +56,9 @@ struct pt_scene {
     int device = 0;
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
     DevBuf rng, spill, tilebuf, colors, pixcnt;       // work buffers, grown on demand
+    DevBuf wfState, wfCtl, wfCtr, wfSpill;            // wavefront variant
+    int variant = 0;                                  // 0 megakernel, 1 wavefront (pt_set_variant)
+    int numCU = 256;
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
@@ -80,7 +83,7 @@ int pt_device_count(void) {
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
     DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals,
-                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt};
+                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -269,6 +272,10 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->numCU = prop.multiProcessorCount;
+    }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { fail(-2, "hipEventCreate failed"); pt_scene_destroy(s); return nullptr; }
     return s;
 }
@@ -306,6 +313,53 @@ static int check_render_args(pt_scene* s, const pt_camera* cam, int spp, int int
     return 0;
 }
 
+// The wavefront variant of render_tiles: logic / trace kernel pairs until no path is alive.
+static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
+                                  const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream) {
+    if (s->armless) return fail(-3, "the wavefront variant needs every material to have a dispatch arm (pt_path.h); use the megakernel");
+    WfParams W;
+    W.n = t.count * 64; W.w = w; W.h = h; W.tileFirst = t.first; W.tileStride = t.stride; W.tilesX = t.tilesX;
+    if (int r = s->wfState.ensure(wf_state_bytes(W.n))) return r;
+    if (int r = s->wfCtl.ensure(64)) return r;
+    wf_carve(W, s->wfState.p);
+    W.qctl = (uint32_t*)s->wfCtl.p;
+    W.rng = (uint32_t*)s->rng.p; W.out = (float4*)d_tiles;
+    W.pathCtr = nullptr;
+    if (count) {
+        if (int r = s->wfCtr.ensure((size_t)W.n * 8 * sizeof(uint32_t))) return r;
+        W.pathCtr = (uint32_t*)s->wfCtr.p;
+    }
+    const int blocks = std::max(1, std::min(s->numCU * 4, (W.n + 255) / 256));
+    int32_t* spill = nullptr;
+    if (s->ds.stackSpill > 0) {
+        if (int r = s->wfSpill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
+        spill = (int32_t*)s->wfSpill.p;
+    }
+    const CamK ck = cam_to_kernel(*cam);
+    HIP_OK(hipMemsetAsync(W.qctl, 0, 16, stream));
+    HIP_OK(hipEventRecord(s->ev0, stream));
+    HIP_OK(launch_wf_init(W, spp, stream));
+    // Paths end at different iterations; the host polls the queue length every 16 iterations.
+    const long long cap = (long long)std::max(spp, 1) * 4200 + 64;
+    bool finished = false;
+    for (long long it = 0; it < cap; it++) {
+        HIP_OK(launch_wf_logic(integrator, count, W, s->ds, ck, maxDepth, useMIS, (int)(it & 1), stream));
+        if ((it & 15) == 15) {
+            uint32_t queued = 0;
+            HIP_OK(hipMemcpyAsync(&queued, W.qctl + (it & 1) * 2, 4, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            if (queued == 0) { finished = true; break; }
+        }
+        HIP_OK(launch_wf_trace(count, blocks, W, s->ds, s->cacheNodes, s->cacheTris, spill, (int)(it & 1), stream));
+    }
+    if (!finished) return fail(-4, "wavefront render did not terminate within %lld iterations", cap);
+    HIP_OK(launch_wf_finish(W, stream));
+    if (count) HIP_OK(launch_wf_counters(W, d_pixcnt, (unsigned long long*)s->totals.p, stream));
+    HIP_OK(hipEventRecord(s->ev1, stream));
+    s->evPending = true;
+    return 0;
+}
+
 // rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
 static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
                         uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool timeIt) {
@@ -316,6 +370,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (s->ds.stackSpill > 0)
         if (int r = s->spill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
     HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
+    if (s->variant == 1) return render_tiles_wavefront(s, cam, w, h, spp, maxDepth, integrator, useMIS, t, d_tiles, d_pixcnt, count, stream);
     KParams P;
     P.S = s->ds;
     P.cam = cam_to_kernel(*cam);
@@ -410,6 +465,13 @@ int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, 
 int pt_render(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
               const pt_tile_range* tiles, float* out) {
     return pt_render_counted(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, nullptr);
+}
+
+int pt_set_variant(pt_scene* s, int variant) {
+    if (!s) return fail(-1, "null scene");
+    if (variant != 0 && variant != 1) return fail(-1, "unknown variant %d (0 = megakernel, 1 = wavefront)", variant);
+    s->variant = variant;
+    return 0;
 }
 
 int pt_get_counters(pt_scene* s, pt_counters* out) {

@@ -34,6 +34,30 @@ struct KParams {
 
 struct TileSpan { int first, stride, count, tilesX; };
 
+// ---- wavefront variant (pt_wavefront.hip) ----
+#ifndef PT_WF_REFILL_LANES
+#define PT_WF_REFILL_LANES 16     // a wave refills from the ray queue once this many lanes are idle
+#endif
+constexpr int kWfRefillLanes = PT_WF_REFILL_LANES;
+struct WfParams {
+    float* F;            // [F_COUNT][n] path state, float fields
+    uint32_t* U;         // [U_COUNT][n] path state, integer fields
+    float* R;            // [R_COUNT][2n] per-ray results (extension ray of path p: p; shadow ray: n + p)
+    uint32_t* queue;     // [2n] compacted ray ids of the current iteration
+    uint32_t* qctl;      // {count, cursor} x 2 (ping-pong by iteration parity)
+    uint32_t* pathCtr;   // [8][n] per-path work counters (COUNT builds) or null
+    uint32_t* rng;       // [tile][6][64] as the megakernel
+    float4* out;         // [tile][64] tile buffer
+    int n, w, h, tileFirst, tileStride, tilesX;
+};
+size_t wf_state_bytes(int n);
+void wf_carve(WfParams& W, void* base);
+hipError_t launch_wf_init(const WfParams& W, int spp, hipStream_t s);
+hipError_t launch_wf_finish(const WfParams& W, hipStream_t s);
+hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s);
+hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int it, hipStream_t s);
+hipError_t launch_wf_counters(const WfParams& W, uint32_t* pixCounters, unsigned long long* totals, hipStream_t s);
+
 // Launchers (asynchronous on `stream`); defined in pt_kernels.hip.
 hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w, int h, TileSpan t, uint32_t* rng, hipStream_t stream);
 // syncShadow: trace the NEE shadow ray inside the bounce (needed only for materials without a dispatch arm)

@@ -145,6 +145,12 @@ int pt_render_counted(pt_scene* scene, const pt_camera* camera, int w, int h, in
                       int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles,
                       float* out_rgba_sum, uint32_t* out_counters);
 
+/* Kernel organisation used by every later render of this scene: 0 = megakernel (default: one wave
+ * per 8x8 tile, all samples and bounces inside one launch), 1 = wavefront (stream-compacted: path
+ * state in HBM, one logic + one traversal launch per bounce; BASELINE config 5's divergence A/B).
+ * Results are bit-identical. */
+int pt_set_variant(pt_scene* scene, int variant);
+
 int pt_get_counters(pt_scene* scene, pt_counters* out);
 int pt_reset_counters(pt_scene* scene);
 /* Device time (ms) of the most recent megakernel launch on this scene, from HIP events recorded

@@ -198,6 +198,43 @@ def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator):
     assert cnt[..., 5].sum() > 100
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_wavefront_variant_matches_golden(api, gpu_ready, case):
+    """the stream-compacted variant must give the megakernel's image and counters."""
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    hs = api.HostScene(golden_scene(str(g["scene"])))
+    sc = api.Scene(hs).set_variant("wavefront")
+    w, h = int(g["w"]), int(g["h"])
+    col, cnt = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]), counters=True)
+    assert np.array_equal(cnt, g["counters"]), case
+    assert_bits_equal(col, g["colors"], case)
+
+
+def test_wavefront_variant_fresh_scenes(api, oracle, gpu_ready, scene_dir):
+    from cudapathtracer_amd import scenes
+    cfgs = [scenes.blob_in_box(os.path.join(scene_dir, "blob3w"), 45, 27, 3, 6, subdiv=3, name="blob3w")["config"],
+            scenes.cornell(os.path.join(scene_dir, "cl3"), 24, 24, 6, 12, ceiling_light=True, tall_material=18, short_material=8, nested=True, name="cl3")["config"]]
+    for cfg in cfgs:
+        gs, hs, osc = _scene_pair(api, oracle, cfg)
+        gs.set_variant("wavefront")
+        i = hs.info
+        col, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], counters=True)
+        ocol, ocnt, _ = osc.render(counters=True, threads=8)
+        assert np.array_equal(cnt, ocnt), cfg
+        assert_bits_equal(col, ocol, cfg)
+    arr = _chain_arrays(api)                       # deep tree: global stack spill inside the persistent trace kernel
+    gs, osc = api.Scene.from_arrays(arr).set_variant("wavefront"), oracle.OracleScene(arrays=arr)
+    cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
+    col, cnt = gs.render(cam, 24, 16, 4, 5, counters=True)
+    ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=24, height=16, spp=4, max_depth=5, integrator=0, counters=True)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col, ocol, "deep chain, wavefront")
+    tiles = np.zeros_like(col)                     # tile sharding works for the variant too
+    for r in range(2):
+        gs.render(cam, 24, 16, 4, 5, tiles=api.rank_tiles(24, 16, r, 2), out=tiles)
+    assert_bits_equal(tiles, col, "wavefront tile sharding")
+
+
 def test_tile_ranges_and_accumulation(api, gpu_ready):
     hs = api.HostScene(golden_scene("cornell64"))
     sc = api.Scene(hs)
