@@ -329,12 +329,17 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
         if (int r = s->wfCtr.ensure((size_t)W.n * 8 * sizeof(uint32_t))) return r;
         W.pathCtr = (uint32_t*)s->wfCtr.p;
     }
-    const int blocks = std::max(1, std::min(s->numCU * 4, (W.n + 255) / 256));
+    const int blocks = std::max(1, std::min(s->numCU * kWfBlocksPerCU, (W.n + 255) / 256));
+    const int spillPerLane = std::max(0, s->stackNeed - kWfStackLds);
     int32_t* spill = nullptr;
-    if (s->ds.stackSpill > 0) {
-        if (int r = s->wfSpill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
+    if (spillPerLane > 0) {
+        if (int r = s->wfSpill.ensure((size_t)blocks * 4 * spillPerLane * 64 * sizeof(int32_t))) return r;
         spill = (int32_t*)s->wfSpill.p;
     }
+    // the trace kernel has its own LDS budget (no medium stacks, smaller traversal stack)
+    int wfNodes, wfTris;
+    if ((size_t)s->nInternal * 64 + (size_t)s->ds.nTris * 48 <= (size_t)kWfCacheBytes) { wfNodes = s->nInternal; wfTris = s->ds.nTris; }
+    else { wfNodes = std::min(s->nInternal, kWfCacheBytes / 64); wfTris = 0; }
     const CamK ck = cam_to_kernel(*cam);
     HIP_OK(hipMemsetAsync(W.qctl, 0, 16, stream));
     HIP_OK(hipEventRecord(s->ev0, stream));
@@ -350,7 +355,7 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
             HIP_OK(hipStreamSynchronize(stream));
             if (queued == 0) { finished = true; break; }
         }
-        HIP_OK(launch_wf_trace(count, blocks, W, s->ds, s->cacheNodes, s->cacheTris, spill, (int)(it & 1), stream));
+        HIP_OK(launch_wf_trace(count, blocks, W, s->ds, wfNodes, wfTris, spill, spillPerLane, (int)(it & 1), stream));
     }
     if (!finished) return fail(-4, "wavefront render did not terminate within %lld iterations", cap);
     HIP_OK(launch_wf_finish(W, stream));

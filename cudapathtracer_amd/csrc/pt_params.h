@@ -36,9 +36,25 @@ struct TileSpan { int first, stride, count, tilesX; };
 
 // ---- wavefront variant (pt_wavefront.hip) ----
 #ifndef PT_WF_REFILL_LANES
-#define PT_WF_REFILL_LANES 16     // a wave refills from the ray queue once this many lanes are idle
+#define PT_WF_REFILL_LANES 32     // a wave refills from the ray queue once this many lanes are idle
 #endif
+#ifndef PT_WF_STACK_LDS
+#define PT_WF_STACK_LDS 8         // LDS stack entries per lane in the (register-light) trace kernel
+#endif
+#ifndef PT_WF_CACHE_BYTES
+#define PT_WF_CACHE_BYTES 12288   // its scene-cache budget: 8 KB stacks + 12 KB cache = 8 workgroups per CU
+#endif
+#ifndef PT_WF_BLOCKS_PER_CU
+#define PT_WF_BLOCKS_PER_CU 8     // persistent grid = CUs x this
+#endif
+#ifndef PT_WF_CHUNK
+#define PT_WF_CHUNK 0             // ray ids claimed per atomic; 0 = exactly the idle lanes (fastest measured)
+#endif
+constexpr int kWfChunk = PT_WF_CHUNK;
 constexpr int kWfRefillLanes = PT_WF_REFILL_LANES;
+constexpr int kWfStackLds = PT_WF_STACK_LDS;
+constexpr int kWfCacheBytes = PT_WF_CACHE_BYTES;
+constexpr int kWfBlocksPerCU = PT_WF_BLOCKS_PER_CU;
 struct WfParams {
     float* F;            // [F_COUNT][n] path state, float fields
     uint32_t* U;         // [U_COUNT][n] path state, integer fields
@@ -55,7 +71,7 @@ void wf_carve(WfParams& W, void* base);
 hipError_t launch_wf_init(const WfParams& W, int spp, hipStream_t s);
 hipError_t launch_wf_finish(const WfParams& W, hipStream_t s);
 hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s);
-hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int it, hipStream_t s);
+hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it, hipStream_t s);
 hipError_t launch_wf_counters(const WfParams& W, uint32_t* pixCounters, unsigned long long* totals, hipStream_t s);
 
 // Launchers (asynchronous on `stream`); defined in pt_kernels.hip.

@@ -172,10 +172,7 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
 // iteration (nothing else touches it while this kernel runs).
 template <bool COUNT>
 __global__ void __launch_bounds__(256)
-#if PT_MIN_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
-#endif
-wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_t* spill, int it) {
+wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
     // stage the scene cache exactly like the megakernel
     typedef __attribute__((address_space(3))) f4v lds_f4;
@@ -191,33 +188,44 @@ wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_
     SceneCache SC; SC.nodes = (lds_cf4*)dstN; SC.nNodes = cacheNodes; SC.tris = (lds_cf4*)dstT; SC.nTris = cacheTris;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cacheBytes = cacheNodes * 64 + cacheTris * 48;
-    Stack<kStackLds> st;
-    st.lds = (lds_i32*)(wf_smem + cacheBytes) + wave * (kStackLds * 64) + lane;
-    st.spill = spill ? spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
+    Stack<kWfStackLds> st;
+    st.lds = (lds_i32*)(wf_smem + cacheBytes) + wave * (kWfStackLds * 64) + lane;
+    st.spill = spill ? spill + ((size_t)(blockIdx.x * 4 + wave) * spillPerLane) * 64 + lane : nullptr;
     st.sp = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { W.qctl[((it + 1) & 1) * 2 + 0] = 0u; W.qctl[((it + 1) & 1) * 2 + 1] = 0u; }
 
     const uint32_t total = W.qctl[(it & 1) * 2 + 0];
     uint32_t* cursor = &W.qctl[(it & 1) * 2 + 1];
     const size_t n = W.n;
-    Trav<kStackLds> tr;
+    Trav<kWfStackLds> tr;
     Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
     bool active = false;
-    bool drained = false;           // wave-uniform: the queue has no more rays for this wave
+    // A refill claims exactly the idle lanes' worth of ray ids with one wave-level atomic
+    // (kWfChunk == 0). Claiming larger chunks per atomic (kWfChunk > 0) measured SLOWER: one launch
+    // only holds a few hundred rays per resident wave, so chunks unbalance the waves.
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool drained = false;           // wave-uniform: global queue exhausted and local chunk empty
     uint32_t ray = 0;
     while (true) {
-        // ---- refill idle lanes (when enough are idle to amortise the atomic, or all are) ----
+        // ---- refill idle lanes (when enough are idle to amortise the ray fetch, or all are) ----
         const unsigned long long idle = __ballot(!active);
         const int nIdle = __popcll(idle);
         if (!drained && (nIdle >= kWfRefillLanes || nIdle == 64)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cursor, (uint32_t)nIdle);
-            base = __shfl(base, 0, 64);
-            if (base + (uint32_t)nIdle >= total) drained = true;
+            if (chunkPos == chunkEnd) {
+                uint32_t base = 0;
+                const uint32_t claim = kWfChunk > 0 ? (uint32_t)kWfChunk : (uint32_t)nIdle;
+                if (lane == 0) base = atomicAdd(cursor, claim);
+                base = __shfl(base, 0, 64);
+                chunkPos = base < total ? base : total;
+                chunkEnd = (base + claim < total) ? base + claim : total;
+                if (chunkPos == chunkEnd) drained = true;
+            }
+            const uint32_t avail = chunkEnd - chunkPos;
+            const uint32_t take = avail < (uint32_t)nIdle ? avail : (uint32_t)nIdle;
             if (!active) {
-                const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (q < total) {
-                    ray = W.queue[q];
+                const uint32_t k = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (k < take) {
+                    ray = W.queue[chunkPos + k];
                     const bool sh = ray >= (uint32_t)n;
                     const uint32_t p = sh ? ray - (uint32_t)n : ray;
                     const float* F = W.F + p;
@@ -229,6 +237,7 @@ wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_
                     active = true;
                 }
             }
+            chunkPos += take;
         }
         if (__ballot(active) == 0ull) { if (drained) break; else continue; }
         // ---- one traversal step (to and through the next leaf) for every lane that holds a ray ----
@@ -295,10 +304,10 @@ hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const 
     }
     return hipGetLastError();
 }
-hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int it, hipStream_t s) {
-    const unsigned lds = (unsigned)((size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)kStackLds * 256);
-    if (count) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, it);
-    else hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, it);
+hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it, hipStream_t s) {
+    const unsigned lds = (unsigned)((size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)kWfStackLds * 256);
+    if (count) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, spillPerLane, it);
+    else hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, spillPerLane, it);
     return hipGetLastError();
 }
 
