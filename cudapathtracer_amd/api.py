@@ -174,7 +174,8 @@ class HostScene:
 
     _ARRAYS = {"points": ("positions", "n_positions", 16), "normals": ("normals", "n_normals", 16), "uvs": ("uvs", "n_uvs", 8),
                "mesh": ("triangles", "n_triangles", 80), "lights": ("lights", "n_lights", 80), "bvh": ("bvh", "n_nodes", 48),
-               "indices": ("bvh_indices", "n_triangles", 4), "materials": ("materials", "n_materials", 176)}
+               "indices": ("bvh_indices", "n_triangles", 4), "materials": ("materials", "n_materials", 176),
+               "textures": ("textures", "n_texels", 16)}
 
     def __init__(self, config_path, base_dir=None, render_number=0):
         self.h = lib().novum_scene_load(config_path.encode(), base_dir.encode() if base_dir else None, render_number)

@@ -420,6 +420,36 @@ void make_camera(bool pinhole, const float pos[3], const float rot[3], float fov
     c.up = unit(rotZ(rotY(rotX(F3{0, 1, 0}, c.xRot), c.yRot), c.zRot));
 }
 
+// ---- textures (imageUtil.cu:144-195, main.cu:364-391) ---------------------------------------------
+// loadBMPToImage(path, isData = false): 24-bit BMP only; pixel rows are read straight after the two
+// packed headers (54 bytes; bfOffBits is not honoured), padded to 4 bytes; row y of the file becomes
+// image row height-1-y; channel/255 then powf(., 2.2f) (host libm, like the reference); alpha 1.
+// Anything else — missing file included — is the reference's Image(0,0).
+bool load_bmp(const std::string& file, std::vector<pt_float4>& px, int& w, int& h) {
+    w = h = 0;
+    FILE* f = fopen(file.c_str(), "rb");
+    if (!f) return false;
+    unsigned char hd[54];
+    bool ok = fread(hd, 1, 54, f) == 54 && hd[0] == 'B' && hd[1] == 'M';
+    uint16_t bpp = 0; int32_t bw = 0, bh = 0;
+    if (ok) { std::memcpy(&bpp, hd + 28, 2); std::memcpy(&bw, hd + 18, 4); std::memcpy(&bh, hd + 22, 4); ok = bpp == 24 && bw > 0 && bh > 0; }
+    if (ok) {
+        const int row = (3 * bw + 3) & ~3;
+        std::vector<unsigned char> line(row);
+        px.assign((size_t)bw * bh, pt_float4{0, 0, 0, 0});
+        for (int y = 0; y < bh; y++) {
+            if (fread(line.data(), 1, row, f) != (size_t)row) std::fill(line.begin(), line.end(), (unsigned char)0);
+            for (int x = 0; x < bw; x++) {
+                float b = line[x * 3 + 0] / 255.0f, g = line[x * 3 + 1] / 255.0f, r = line[x * 3 + 2] / 255.0f;
+                px[(size_t)(bh - 1 - y) * bw + x] = pt_float4{powf(r, 2.2f), powf(g, 2.2f), powf(b, 2.2f), 1.0f};
+            }
+        }
+        w = bw; h = bh;
+    }
+    fclose(f);
+    return ok;
+}
+
 // ---- image output (imageUtil.cu:69-100, 202-232) --------------------------------------------------
 float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 float aces(float c) { return clamp01((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f)); }
@@ -437,10 +467,18 @@ novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int
     else { std::string p = config_path; size_t k = p.find_last_of('/'); base = (k == std::string::npos) ? "." : p.substr(0, k); }
     const Config& c = S->cfg;
     make_camera(c.pinhole, c.camPos, c.camRot, c.fov, c.aperture, c.focalDist, c.width, c.height, S->cam);
-    // The four texture BMPs of main.cu:371-374 are absent offline: loadBMPToImage returns 0x0
-    // images (imageUtil.cu:146-149), i.e. every start index and size is 0.
-    const int zeros[4] = {0, 0, 0, 0};
-    material_table(*S, zeros, zeros, zeros);
+    // The four fixed texture files of main.cu:371-374, concatenated (main.cu:376-386); a missing
+    // file is a 0x0 image (imageUtil.cu:146-149). Paths are taken relative to base_dir.
+    static const char* kTextures[4] = {"textures/enkidutexture.bmp", "textures/enkiduchibitexture.bmp", "textures/leaftex2.bmp", "textures/leafautumn.bmp"};
+    int tStart[4], tW[4], tH[4], cursor = 0;
+    for (int i = 0; i < 4; i++) {
+        std::vector<pt_float4> px;
+        load_bmp(base + "/" + kTextures[i], px, tW[i], tH[i]);
+        S->textures.insert(S->textures.end(), px.begin(), px.end());
+        tStart[i] = cursor;
+        cursor += tW[i] * tH[i];
+    }
+    material_table(*S, tStart, tW, tH);
     for (const MeshLine& m : c.meshes) {
         std::string p = (!m.path.empty() && m.path[0] == '/') ? m.path : base + "/" + m.path;
         float e[3] = {m.mult * m.rgb[0], m.mult * m.rgb[1], m.mult * m.rgb[2]};

@@ -10,7 +10,8 @@ namespace oracle {
 // ---- oracle_scene.cpp -------------------------------------------------------
 bool loadConfig(const std::string& filepath, RenderConfig& config);                 // objects.cuh:844-943
 void readObjSimple(const std::string& filename, Scene& sc, float4 e, int materialID, float4 offset);  // main.cu:936-1068
-void buildMaterialTable(Scene& sc);                                                 // main.cu:397-467
+void buildMaterialTable(Scene& sc, const int startIndices[4], const int widths[4], const int heights[4]);   // main.cu:397-467
+void loadTextures(Scene& sc, const std::string& baseDir, int startIndices[4], int widths[4], int heights[4]);   // main.cu:364-391 + imageUtil.cu:144-195
 void buildSceneBVH(Scene& sc, int maxLeafSize);                                     // main.cu:20-233, 502-530
 Camera cameraPinhole(const float4& origin, int w, int h, float xR, float yR, float zR, float FOV, float aajitter = 2.0f);   // objects.cuh:221-242
 Camera cameraNotPinhole(const float4& origin, int w, int h, float xR, float yR, float zR, float FOV, float aperture, float focalDist, float aajitter = 2.0f);  // objects.cuh:244-264

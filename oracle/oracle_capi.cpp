@@ -29,7 +29,7 @@ void* oracle_scene_load(const char* configPath, const char* baseDir, int renderN
 // main.cu:469-557): lets tests hand-build trees the SAH builder would never produce.
 void* oracle_scene_from_arrays(const void* points, int nPoints, const void* normals, int nNormals, const void* uvs, int nUvs,
                                const void* mesh, int nTris, const void* lights, int nLights, const void* bvh, int nNodes,
-                               const int* indices, const void* mats, int nMats) {
+                               const int* indices, const void* mats, int nMats, const void* textures, int nTexels) {
     OracleScene* s = new OracleScene();
     s->sc.points.assign((const float4*)points, (const float4*)points + nPoints);
     s->sc.normals.assign((const float4*)normals, (const float4*)normals + nNormals);
@@ -39,12 +39,15 @@ void* oracle_scene_from_arrays(const void* points, int nPoints, const void* norm
     s->sc.bvh.assign((const BVHnode*)bvh, (const BVHnode*)bvh + nNodes);
     s->sc.indices.assign(indices, indices + nTris);
     s->sc.mats.assign((const Material*)mats, (const Material*)mats + nMats);
+    if (textures && nTexels > 0) s->sc.textures.assign((const float4*)textures, (const float4*)textures + nTexels);
     s->cfg.integratorType = "UNIDIRECTIONAL";
     s->cam = cameraPinhole(f4(0.0f, 0.0f, 1.0f), 8, 8, 0.0f, 0.0f, 0.0f, 60.0f);
     return s;
 }
 
 void oracle_scene_free(void* h) { delete (OracleScene*)h; }
+
+int oracle_scene_texels(void* h) { return (int)((OracleScene*)h)->sc.textures.size(); }
 
 // info[0..15]: width,height,spp,maxDepth,integrator,leafSize,nTris,nLights,nNodes,nPoints,
 //              nNormals,nUvs,nMats,largestLeaf,backupCount,treeDepth
@@ -75,6 +78,7 @@ void oracle_scene_get(void* h, int what, void* dst) {
         case 6: std::memcpy(dst, s->sc.indices.data(), s->sc.indices.size() * sizeof(int)); break;
         case 7: std::memcpy(dst, s->sc.mats.data(), s->sc.mats.size() * sizeof(Material)); break;
         case 8: std::memcpy(dst, &s->cam, sizeof(Camera)); break;
+        case 9: std::memcpy(dst, s->sc.textures.data(), s->sc.textures.size() * sizeof(float4)); break;
         default: break;
     }
 }

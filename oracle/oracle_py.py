@@ -39,7 +39,9 @@ def lib():
         L.oracle_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.oracle_scene_from_arrays.restype = C.c_void_p
         L.oracle_scene_from_arrays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_scene_texels.restype = C.c_int
+        L.oracle_scene_texels.argtypes = [C.c_void_p]
         L.oracle_scene_free.argtypes = [C.c_void_p]
         L.oracle_scene_info.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_scene_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -79,7 +81,9 @@ class OracleScene:
             self.h = lib().oracle_scene_from_arrays(_p(a["points"]), a["points"].size // 16, _p(a["normals"]), a["normals"].size // 16,
                                                     _p(a["uvs"]), a["uvs"].size // 8, _p(a["mesh"]), a["mesh"].size // 80,
                                                     _p(a["lights"]), a["lights"].size // 80, _p(a["bvh"]), a["bvh"].size // 48,
-                                                    _p(a["indices"]), _p(a["materials"]), a["materials"].size // 176)
+                                                    _p(a["indices"]), _p(a["materials"]), a["materials"].size // 176,
+                                                    _p(a["textures"]) if "textures" in a and a["textures"].size else None,
+                                                    a["textures"].size // 16 if "textures" in a else 0)
         else:
             base = base_dir if base_dir is not None else os.path.dirname(os.path.abspath(config_path))
             self.h = lib().oracle_scene_load(config_path.encode(), base.encode(), render_number)
@@ -101,6 +105,10 @@ class OracleScene:
             pass
 
     def array(self, what):
+        if what == "textures":
+            buf = np.zeros(lib().oracle_scene_texels(self.h) * 16, np.uint8)
+            lib().oracle_scene_get(self.h, 9, _p(buf))
+            return buf
         spec = {"points": (0, "n_points", 16), "normals": (1, "n_normals", 16), "uvs": (2, "n_uvs", 8),
                 "mesh": (3, "n_tris", 80), "lights": (4, "n_lights", 80), "bvh": (5, "n_nodes", 48),
                 "indices": (6, "n_tris", 4), "materials": (7, "n_mats", 176)}[what]

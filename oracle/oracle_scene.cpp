@@ -245,10 +245,51 @@ static Material matMirror() {
     return m;
 }
 
-// main.cu:397-467. The four texture BMPs (main.cu:371-374) do not exist offline, so every
-// texture is 0x0 at start index 0 exactly as `loadBMPToImage` returns on a missing file.
-void buildMaterialTable(Scene& sc) {
-    int startIndices[4] = {0, 0, 0, 0}, widths[4] = {0, 0, 0, 0}, heights[4] = {0, 0, 0, 0};
+// imageUtil.cu:144-195 loadBMPToImage(path, isData=false): 24-bit BMP, rows read straight after the
+// 54 header bytes (bfOffBits is ignored), each row padded to 4 bytes, y flipped, channels /255
+// then pow(., 2.2) with the host libm, alpha 1. Missing / non-BMP / non-24-bit file -> 0x0 image.
+static bool loadBMPToImage(const std::string& filename, std::vector<float4>& pixels, int& width, int& height) {
+    width = height = 0;
+    std::ifstream in(filename, std::ios::binary);
+    if (!in.is_open()) return false;
+    unsigned char hd[54];
+    in.read(reinterpret_cast<char*>(hd), 54);
+    if (!in || hd[0] != 'B' || hd[1] != 'M') return false;
+    uint16_t bpp; std::memcpy(&bpp, hd + 28, 2);
+    if (bpp != 24) return false;
+    int32_t w, h; std::memcpy(&w, hd + 18, 4); std::memcpy(&h, hd + 22, 4);
+    if (w <= 0 || h <= 0) return false;
+    int rowSize = (3 * w + 3) & (~3);
+    std::vector<unsigned char> row(rowSize);
+    pixels.assign((size_t)w * h, f4());
+    for (int y = 0; y < h; y++) {
+        in.read(reinterpret_cast<char*>(row.data()), rowSize);
+        for (int x = 0; x < w; x++) {
+            float b = row[x * 3 + 0] / 255.0f, g = row[x * 3 + 1] / 255.0f, r = row[x * 3 + 2] / 255.0f;
+            r = powf(r, 2.2f); g = powf(g, 2.2f); b = powf(b, 2.2f);
+            pixels[(size_t)(h - 1 - y) * w + x] = f4(r, g, b, 1.0f);
+        }
+    }
+    width = w; height = h;
+    return true;
+}
+
+// main.cu:364-391: the four fixed textures, concatenated; a missing file contributes a 0x0 image.
+void loadTextures(Scene& sc, const std::string& baseDir, int startIndices[4], int widths[4], int heights[4]) {
+    const char* names[4] = {"textures/enkidutexture.bmp", "textures/enkiduchibitexture.bmp", "textures/leaftex2.bmp", "textures/leafautumn.bmp"};
+    sc.textures.clear();
+    int cur = 0;
+    for (int i = 0; i < 4; i++) {
+        std::vector<float4> px; int w, h;
+        loadBMPToImage((baseDir.empty() ? std::string() : baseDir + "/") + names[i], px, w, h);
+        sc.textures.insert(sc.textures.end(), px.begin(), px.end());
+        widths[i] = w; heights[i] = h; startIndices[i] = cur;
+        cur += w * h;
+    }
+}
+
+// main.cu:397-467.
+void buildMaterialTable(Scene& sc, const int startIndices[4], const int widths[4], const int heights[4]) {
     Material lambertTextured = matDiffuseTextured(startIndices[0], widths[0], heights[0]);
     Material lambert2Textured = matDiffuseTextured(startIndices[1], widths[1], heights[1]);
     Material lambertBlue = matDiffuse(f4(0.4f, 0.4f, 0.8f));
@@ -512,7 +553,9 @@ bool loadSceneFromConfig(const std::string& configPath, const std::string& baseD
         cam = cameraPinhole(cfg.camPos, cfg.width, cfg.height, cfg.camRot.x, cfg.camRot.y, cfg.camRot.z, cfg.camFov);
     else
         cam = cameraNotPinhole(cfg.camPos, cfg.width, cfg.height, cfg.camRot.x, cfg.camRot.y, cfg.camRot.z, cfg.camFov, cfg.camApeture, cfg.camFocalDist);
-    buildMaterialTable(sc);
+    int starts[4], tw[4], th[4];
+    loadTextures(sc, baseDir, starts, tw, th);
+    buildMaterialTable(sc, starts, tw, th);
     for (const MeshConfig& m : cfg.meshes) {
         std::string p = (baseDir.empty() || (!m.path.empty() && m.path[0] == '/')) ? m.path : baseDir + "/" + m.path;
         float4 e = m.emissionMultiplier * m.emissionColor;

@@ -38,8 +38,13 @@ def scene_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("scenes"))
 
 
-def golden_scene(name):
-    return os.path.join(GOLDEN, "scenes", name + ".rendertron")
+def golden_scene(name, sub="scenes"):
+    return os.path.join(GOLDEN, sub, name + ".rendertron")
+
+
+def golden_case_scene(g):
+    """Config path of a golden .npz (older fixtures have no scene_dir field: they live in scenes/)."""
+    return golden_scene(str(g["scene"]), str(g["scene_dir"]) if "scene_dir" in g else "scenes")
 
 
 @pytest.fixture(scope="session")

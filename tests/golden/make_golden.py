@@ -30,18 +30,22 @@ CASES = [
     ("mixed32_mis", dict(width=32, height=32, spp=8, max_depth=6, tall_material=19, short_material=5, nested=True, name="mixed32"), dict(integrator=0)),
     ("mixed32_naive", dict(width=32, height=32, spp=8, max_depth=6, tall_material=19, short_material=5, nested=True, name="mixed32"), dict(integrator=2)),
     ("metal32_mis", dict(width=40, height=24, spp=8, max_depth=5, tall_material=4, short_material=7, name="metal32"), dict(integrator=0)),
+    # textured Lambert (11, 12) + leaf materials (13, 16) with procedural BMP textures; own directory
+    ("textured32_mis", dict(gen="textured", sub="scenes_tex", width=32, height=24, spp=8, max_depth=5, name="textured32"), dict(integrator=0)),
+    ("textured32_naive", dict(gen="textured", sub="scenes_tex", width=32, height=24, spp=8, max_depth=5, name="textured32"), dict(integrator=2)),
 ]
 
 
 def main():
-    sdir = os.path.join(HERE, "scenes")
     for name, skw, rkw in CASES:
-        s = scenes.cornell(sdir, **skw)
+        skw = dict(skw)
+        sdir = os.path.join(HERE, skw.pop("sub", "scenes"))
+        s = getattr(scenes, skw.pop("gen", "cornell"))(sdir, **skw)
         sc = O.OracleScene(s["config"])
         col, cnt, _ = sc.render(counters=True, threads=4, **rkw)
         i = sc.info
         np.savez_compressed(os.path.join(HERE, name + ".npz"), colors=col, counters=cnt, w=i["width"], h=i["height"], spp=i["spp"],
-                            max_depth=i["max_depth"], integrator=rkw["integrator"], seed=103033, scene=skw["name"],
+                            max_depth=i["max_depth"], integrator=rkw["integrator"], seed=103033, scene=skw["name"], scene_dir=os.path.basename(sdir),
                             scene_sha256=s["sha256"])
         print(name, "mean", col[..., :3].mean(), "rays", int(cnt[..., 0].sum() + cnt[..., 1].sum()))
     kat = {}

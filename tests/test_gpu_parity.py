@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_scene
+from conftest import GOLDEN, golden_case_scene, golden_scene
 from util import assert_bits_equal, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -159,7 +159,7 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 
 @pytest.mark.parametrize("case", CASES)
 def test_render_matches_golden(api, gpu_ready, case):
     g = np.load(os.path.join(GOLDEN, case + ".npz"))
-    hs = api.HostScene(golden_scene(str(g["scene"])))
+    hs = api.HostScene(golden_case_scene(g))
     sc = api.Scene(hs)
     w, h = int(g["w"]), int(g["h"])
     col, cnt = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]), counters=True)
@@ -202,7 +202,7 @@ def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator):
 def test_wavefront_variant_matches_golden(api, gpu_ready, case):
     """the stream-compacted variant must give the megakernel's image and counters."""
     g = np.load(os.path.join(GOLDEN, case + ".npz"))
-    hs = api.HostScene(golden_scene(str(g["scene"])))
+    hs = api.HostScene(golden_case_scene(g))
     sc = api.Scene(hs).set_variant("wavefront")
     w, h = int(g["w"]), int(g["h"])
     col, cnt = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]), counters=True)

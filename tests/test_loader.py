@@ -7,7 +7,7 @@ import pytest
 
 from conftest import golden_scene
 
-ARRAYS = ["points", "normals", "uvs", "mesh", "lights", "bvh", "indices", "materials"]
+ARRAYS = ["points", "normals", "uvs", "mesh", "lights", "bvh", "indices", "materials", "textures"]
 
 
 def _same(api, oracle, cfg, render_number=0):
@@ -27,6 +27,18 @@ def _same(api, oracle, cfg, render_number=0):
 @pytest.mark.parametrize("name", ["cornell32", "mixed32", "metal32"])
 def test_golden_scenes_load_identically(api, oracle, name):
     _same(api, oracle, golden_scene(name))
+
+
+def test_textures_load_identically(api, oracle):
+    """imageUtil.cu:144-195: 24-bit BMPs, row padding, y flip, gamma 2.2 linearisation, concatenation."""
+    hs = _same(api, oracle, golden_scene("textured32", "scenes_tex"))
+    tex = hs.array("textures").view(np.float32).reshape(-1, 4)
+    assert len(tex) == 64 * 48 + 21 * 33 + 32 * 32 * 2 and np.all(tex[:, 3] == 1.0)
+    mats = hs.array("materials")
+    m11 = mats[11 * 176:12 * 176].view(np.int32); m12 = mats[12 * 176:13 * 176].view(np.int32); m16 = mats[16 * 176:17 * 176].view(np.int32)
+    assert (m11[1], m11[2], m11[3]) == (0, 64, 48) and (m12[1], m12[2], m12[3]) == (64 * 48, 21, 33) and m16[1] == 64 * 48 + 21 * 33 + 32 * 32
+    # top-left texel of the checker is (230, 175, 90)/255 ^ 2.2; image row 0 is the TOP of the picture
+    assert np.allclose(tex[0, :3], (np.array([230, 175, 90]) / 255.0) ** 2.2, rtol=1e-5)
 
 
 def test_blob_scene_and_tree_shape(api, oracle, scene_dir):

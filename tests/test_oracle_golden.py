@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_scene
+from conftest import GOLDEN, golden_case_scene, golden_scene
 from util import assert_bits_equal
 
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
@@ -14,7 +14,7 @@ CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 
 @pytest.mark.parametrize("case", CASES)
 def test_oracle_reproduces_golden(oracle, case):
     g = np.load(os.path.join(GOLDEN, case + ".npz"))
-    sc = oracle.OracleScene(golden_scene(str(g["scene"])))
+    sc = oracle.OracleScene(golden_case_scene(g))
     col, cnt, _ = sc.render(spp=int(g["spp"]), max_depth=int(g["max_depth"]), integrator=int(g["integrator"]),
                             seed=int(g["seed"]), counters=True, threads=2)
     assert_bits_equal(col, g["colors"], case)
