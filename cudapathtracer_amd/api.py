@@ -69,6 +69,9 @@ class TileRange(C.Structure):
     _fields_ = [("first", C.c_int32), ("stride", C.c_int32), ("count", C.c_int32)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p)      # pt_progress_fn
+
+
 class PtError(RuntimeError):
     pass
 
@@ -118,6 +121,9 @@ def lib():
     L.novum_make_camera.argtypes = [i32, vp, vp, f32, f32, f32, i32, i32, C.POINTER(Camera)]
     L.novum_finalise.argtypes = [vp, i32, i32]
     L.novum_init_render.argtypes = [C.c_char_p, C.c_char_p, i32, vp, C.c_char_p]
+    L.novum_init_render_progressive.argtypes = [C.c_char_p, C.c_char_p, i32, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, i32]
+    L.novum_save_csv_mono.argtypes = [C.c_char_p, vp, i32, i32, i32]
+    L.pt_launch_progressive.argtypes = [i32, i32, Camera, vp, i32, i32, i32, i32, vp, i32, PROGRESS_FN, vp]
     L.novum_save_bmp.argtypes = [C.c_char_p, vp, i32, i32, i32]
     _lib = L
     return L
@@ -157,14 +163,18 @@ def save_bmp(path, rgba, post_process=True):
         raise PtError("could not write " + path)
 
 
-def init_render(config_path, render_number=0, base_dir=None, bmp_path=None):
-    """initRender (main.cu:235-923) for the unidirectional integrators; returns finalised [h,w,4]."""
+def init_render(config_path, render_number=0, base_dir=None, bmp_path=None, preview_bmp=None, preview_csv=None,
+                interval_seconds=5.0, chunk_spp=0):
+    """initRender (main.cu:235-923) for the unidirectional integrators; returns finalised [h,w,4].
+    With chunk_spp > 0 and a preview path it also writes the reference's progressive preview
+    (render.bmp / renderCSV.csv every interval_seconds, deviceCode.cu:574-604)."""
     hs = HostScene(config_path, base_dir, render_number)
     w, h = hs.info["width"], hs.info["height"]
     hs.close()
     out = np.zeros((h, w, 4), np.float32)
-    rc = lib().novum_init_render(config_path.encode(), base_dir.encode() if base_dir else None, render_number, _p(out),
-                                 bmp_path.encode() if bmp_path else None)
+    enc = lambda s: s.encode() if s else None
+    rc = lib().novum_init_render_progressive(config_path.encode(), enc(base_dir), render_number, _p(out), enc(bmp_path),
+                                             enc(preview_bmp), enc(preview_csv), float(interval_seconds), int(chunk_spp))
     _check(rc, "novum_init_render")
     return out
 
@@ -275,6 +285,12 @@ class Scene:
 
     def launch_unidirectional(self, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr):
         _check(lib().pt_launch_unidirectional(max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr), "pt_launch_unidirectional")
+
+    def launch_progressive(self, integrator, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr, chunk_spp, progress=None):
+        """pt_launch_progressive: progress(samples_done) -> truthy to stop early."""
+        cb = PROGRESS_FN((lambda done, _u: int(bool(progress(done)))) if progress else (lambda done, _u: 0))
+        _check(lib().pt_launch_progressive(integrator, max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr, chunk_spp, cb, None),
+               "pt_launch_progressive")
 
     def launch_naive_unidirectional(self, max_depth, camera, num_sample, use_mis, w, h, d_colors_ptr):
         _check(lib().pt_launch_naive_unidirectional(max_depth, camera, self.h, num_sample, int(use_mis), w, h, d_colors_ptr), "pt_launch_naive_unidirectional")

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -563,11 +564,46 @@ int novum_save_bmp(const char* path, const float* rgba, int w, int h, int post) 
     return 0;
 }
 
+int novum_save_csv_mono(const char* path, const float* rgba, int w, int h, int channel) {      // imageUtil.cu:123-142
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            fprintf(f, "%.3e", (double)rgba[4 * ((size_t)y * w + x) + channel]);       // std::scientific, precision 3
+            if (x < w - 1) fputc(',', f);
+        }
+        fputc('\n', f);
+    }
+    fclose(f);
+    return 0;
+}
+
 // hipMalloc / hipMemset / hipMemcpy / hipFree without pulling the HIP headers into this file
 int pt_host_alloc_zero_(void** p, size_t bytes);
+int pt_host_download_(void* d, void* h, size_t bytes);
 int pt_host_download_free_(void* d, void* h, size_t bytes);
 
-int novum_init_render(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path) {
+namespace {
+struct Preview {                       // the `elapsed >= saveIntervalSeconds` block of deviceCode.cu:574-604
+    void* dColors; std::vector<float>* host; int w, h; bool post;
+    const char* bmp; const char* csv; double interval; double last;
+};
+double now_seconds() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+int preview_cb(int samplesDone, void* user) {
+    Preview* pv = (Preview*)user;
+    double t = now_seconds();
+    if (t - pv->last < pv->interval) return 0;
+    if (pt_host_download_(pv->dColors, pv->host->data(), (size_t)pv->w * pv->h * 16) != 0) return 0;
+    novum_finalise(pv->host->data(), pv->w * pv->h, samplesDone);      // h_colors / (currSample + 1), NaN / Inf painted
+    if (pv->bmp) novum_save_bmp(pv->bmp, pv->host->data(), pv->w, pv->h, pv->post ? 1 : 0);
+    if (pv->csv) novum_save_csv_mono(pv->csv, pv->host->data(), pv->w, pv->h, 0);
+    pv->last = t;
+    return 0;
+}
+}  // namespace
+
+int novum_init_render_progressive(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path,
+                                  const char* preview_bmp, const char* preview_csv, double interval_seconds, int chunk_spp) {
     novum_scene* S = novum_scene_load(config_path, base_dir, render_number);
     if (!S) return -1;
     int integ = integrator_id(S->cfg.integrator);
@@ -586,8 +622,13 @@ int novum_init_render(const char* config_path, const char* base_dir, int render_
     int rc = pt_host_alloc_zero_(&colors, bytes);
     std::vector<float> host((size_t)w * h * 4);
     if (rc == 0) {
-        rc = (integ == PT_UNIDIRECTIONAL) ? pt_launch_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors)     // main.cu:565
-                                          : pt_launch_naive_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors);   // main.cu:677
+        if (chunk_spp > 0 && (preview_bmp || preview_csv)) {
+            Preview pv{colors, &host, w, h, S->cfg.postProcess, preview_bmp, preview_csv, interval_seconds, now_seconds()};
+            rc = pt_launch_progressive(integ, S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors, chunk_spp, preview_cb, &pv);
+        } else {
+            rc = (integ == PT_UNIDIRECTIONAL) ? pt_launch_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors)     // main.cu:565
+                                              : pt_launch_naive_unidirectional(S->cfg.maxDepth, S->cam, dev, S->cfg.spp, 1, w, h, colors);   // main.cu:677
+        }
         int rc2 = pt_host_download_free_(colors, host.data(), bytes);  // main.cu:854-855, 889
         if (rc == 0) rc = rc2;
     }
@@ -599,6 +640,10 @@ int novum_init_render(const char* config_path, const char* base_dir, int render_
     pt_scene_destroy(dev);
     novum_scene_free(S);
     return rc;
+}
+
+int novum_init_render(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path) {
+    return novum_init_render_progressive(config_path, base_dir, render_number, out_rgba, bmp_path, nullptr, nullptr, 0.0, 0);
 }
 
 }  // extern "C"

@@ -367,14 +367,16 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
 
 // rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
 static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
-                        uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool timeIt) {
+                        uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool continueStreams) {
     if (t.count == 0) return 0;
     // the reference keys the stream by the camera's image size (y*w+x with the launch's w, deviceCode.cu:59)
     if (int r = s->rng.ensure((size_t)t.count * 384 * sizeof(uint32_t))) return r;
     int blocks = megakernel_blocks(t.count);
     if (s->ds.stackSpill > 0)
         if (int r = s->spill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
-    HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
+    // continueStreams: a later chunk of a progressive render keeps the per-pixel XORWOW states the
+    // previous chunk stored (the reference reloads / stores them around every sample, deviceCode.cu:294, 541)
+    if (!continueStreams) HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
     if (s->variant == 1) return render_tiles_wavefront(s, cam, w, h, spp, maxDepth, integrator, useMIS, t, d_tiles, d_pixcnt, count, stream);
     KParams P;
     P.S = s->ds;
@@ -385,7 +387,6 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;
-    (void)timeIt;
     HIP_OK(hipEventRecord(s->ev0, stream));            // HIP events on the launch stream, around the megakernel only
     HIP_OK(launch_megakernel(integrator, count, !(s->deferShadow && !s->armless), P, stream));
     HIP_OK(hipEventRecord(s->ev1, stream));
@@ -423,9 +424,34 @@ static int launch_on_colors(pt_scene* s, const pt_camera* cam, int w, int h, int
     if (int r = resolve_tiles(w, h, tiles, t)) return r;
     if (int r = s->tilebuf.ensure(std::max<size_t>((size_t)t.count * 64 * sizeof(float4), 16))) return r;
     HIP_OK(launch_tile(w, h, t, (const float4*)d_colors, (float4*)s->tilebuf.p, nullptr));
-    if (int r = render_tiles(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, t, s->tilebuf.p, d_pixcnt, count, nullptr, true)) return r;
+    if (int r = render_tiles(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, t, s->tilebuf.p, d_pixcnt, count, nullptr, false)) return r;
     HIP_OK(launch_untile(w, h, t, (const float4*)s->tilebuf.p, (float4*)d_colors, nullptr));
     HIP_OK(hipDeviceSynchronize());                 // cudaDeviceSynchronize, deviceCode.cu:608
+    return 0;
+}
+
+// The reference's launchers with their progressive hook (deviceCode.cu:568-606): the sample loop runs
+// in chunks of `chunk_spp`; after every chunk `d_colors` holds the sum over `samples_done` samples and
+// `progress(samples_done, user)` is called on the calling thread (the reference writes render.bmp /
+// renderCSV.csv there every >= 5 s; file I/O stays outside this ABI). The per-pixel streams continue
+// across chunks, so the final image is bit-identical to the one-shot launcher. A non-zero return
+// from `progress` stops the render after that chunk.
+int pt_launch_progressive(int integrator, int maxDepth, pt_camera camera, pt_scene* s, int numSample, int useMIS, int w, int h,
+                          void* d_colors, int chunk_spp, pt_progress_fn progress, void* user) {
+    if (int r = check_render_args(s, &camera, numSample, integrator)) return r;
+    if (chunk_spp <= 0) return fail(-1, "chunk_spp must be positive");
+    TileSpan t;
+    if (int r = resolve_tiles(w, h, nullptr, t)) return r;
+    if (int r = s->tilebuf.ensure(std::max<size_t>((size_t)t.count * 64 * sizeof(float4), 16))) return r;
+    HIP_OK(launch_tile(w, h, t, (const float4*)d_colors, (float4*)s->tilebuf.p, nullptr));
+    for (int done = 0; done < numSample;) {
+        const int n = std::min(chunk_spp, numSample - done);
+        if (int r = render_tiles(s, &camera, w, h, n, maxDepth, integrator, useMIS, 103033ull, t, s->tilebuf.p, nullptr, false, nullptr, done > 0)) return r;
+        HIP_OK(launch_untile(w, h, t, (const float4*)s->tilebuf.p, (float4*)d_colors, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        done += n;
+        if (progress && progress(done, user) != 0) break;
+    }
     return 0;
 }
 
@@ -509,6 +535,10 @@ float pt_last_kernel_ms(pt_scene* s) {
 int pt_host_alloc_zero_(void** p, size_t bytes) {
     HIP_OK(hipMalloc(p, std::max<size_t>(bytes, 16)));
     HIP_OK(hipMemset(*p, 0, bytes));
+    return 0;
+}
+int pt_host_download_(void* d, void* h, size_t bytes) {
+    HIP_OK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 int pt_host_download_free_(void* d, void* h, size_t bytes) {

@@ -139,6 +139,17 @@ int pt_tile_device(int w, int h, const pt_tile_range* tiles, const void* d_color
 int pt_launch_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors);
 int pt_launch_naive_unidirectional(int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h, void* d_colors);
 
+/* The launchers with the reference's progressive hook (the `elapsed >= saveIntervalSeconds` block
+ * inside the sample loop, deviceCode.cu:574-604 / 237-267). The samples run in chunks of
+ * chunk_spp; after each chunk d_colors holds the sum over samples_done samples and
+ * progress(samples_done, user) runs on the calling thread (write a preview there — the reference
+ * writes render.bmp + renderCSV.csv; this ABI does no file I/O). Per-pixel streams continue across
+ * chunks: the final d_colors is bit-identical to pt_launch_[naive_]unidirectional. A non-zero
+ * return from progress ends the render after that chunk. integrator: 0 or 2. */
+typedef int (*pt_progress_fn)(int samples_done, void* user);
+int pt_launch_progressive(int integrator, int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h,
+                          void* d_colors, int chunk_spp, pt_progress_fn progress, void* user);
+
 /* Same as pt_render plus per-pixel counters (w*h x 8 uint32: rays_closest, rays_shadow,
  * node_pops, box_tests, tri_tests, hits, rng_draws, iterations) for parity checks. */
 int pt_render_counted(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
@@ -199,6 +210,15 @@ void novum_finalise(float* rgba, int n, int sample_count);
 int novum_init_render(const char* config_path, const char* base_dir, int render_number, float* out_rgba, const char* bmp_path);
 /* Image::saveImageBMP (imageUtil.cu:69-100): rgba is w*h float4 linear radiance, y = 0 bottom. */
 int novum_save_bmp(const char* path, const float* rgba, int w, int h, int post_process);
+/* Image::saveImageCSV_MONO(channel) (imageUtil.cu:123-142): one channel, scientific, 3 digits. */
+int novum_save_csv_mono(const char* path, const float* rgba, int w, int h, int channel);
+/* initRender with the reference's progressive preview (deviceCode.cu:574-604): renders in chunks of
+ * chunk_spp samples and, whenever at least interval_seconds have passed since the last preview,
+ * writes the running average to preview_bmp (and preview_csv if not NULL), as the reference does with
+ * render.bmp / renderCSV.csv every 5 s. Final image as novum_init_render. */
+int novum_init_render_progressive(const char* config_path, const char* base_dir, int render_number, float* out_rgba,
+                                  const char* bmp_path, const char* preview_bmp, const char* preview_csv,
+                                  double interval_seconds, int chunk_spp);
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,38 @@ def test_reference_launcher_shape_and_init_render(api, oracle, gpu_ready):
     assert_bits_equal(img, oracle.finalise(g["colors"], 8).reshape(32, 32, 4), "novum_init_render")
 
 
+@pytest.mark.parametrize("variant", ["megakernel", "wavefront"])
+def test_progressive_launcher(api, gpu_ready, tmp_path, variant):
+    """chunked rendering with the preview hook equals the one-shot launcher bit for bit."""
+    torch = gpu_ready
+    g = np.load(os.path.join(GOLDEN, "mixed32_mis.npz"))
+    hs = api.HostScene(golden_case_scene(g))
+    sc = api.Scene(hs).set_variant(variant)
+    colors = torch.zeros(32, 32, 4, device="cuda")
+    seen = []
+    sc.launch_progressive(0, int(g["max_depth"]), hs.camera(), int(g["spp"]), True, 32, 32, colors.data_ptr(), 3, lambda done: seen.append(done))
+    assert seen == [3, 6, 8]
+    assert_bits_equal(colors.cpu().numpy(), g["colors"], "progressive == one-shot")
+    colors.zero_()
+    sc.launch_progressive(0, int(g["max_depth"]), hs.camera(), int(g["spp"]), True, 32, 32, colors.data_ptr(), 3, lambda done: done >= 6)
+    part = colors.cpu().numpy()
+    assert not np.array_equal(part, g["colors"]) and np.isfinite(part[..., :3]).all()      # stopped after 6 of 8 samples
+
+
+def test_init_render_with_preview_files(api, oracle, gpu_ready, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "cornell32_mis.npz"))
+    bmp, pbmp, pcsv = str(tmp_path / "final.bmp"), str(tmp_path / "render.bmp"), str(tmp_path / "renderCSV.csv")
+    img = api.init_render(golden_case_scene(g), bmp_path=bmp, preview_bmp=pbmp, preview_csv=pcsv, interval_seconds=0.0, chunk_spp=4)
+    assert_bits_equal(img, oracle.finalise(g["colors"], 8).reshape(32, 32, 4), "init_render with previews")
+    for f in (bmp, pbmp):
+        b = open(f, "rb").read()
+        assert b[:2] == b"BM" and len(b) == 54 + 32 * 32 * 3 and int.from_bytes(b[18:22], "little") == 32
+    rows = open(pcsv).read().strip().split("\n")
+    assert len(rows) == 32 and len(rows[0].split(",")) == 32 and "e" in rows[0].split(",")[0]
+    # last preview = all 8 samples: CSV row 0 is image row y = 0 (bottom), channel 0, 3 significant decimals
+    assert abs(float(rows[5].split(",")[7]) - img[5, 7, 0]) <= 5e-4 * max(1.0, abs(img[5, 7, 0]))
+
+
 def test_device_tile_path_and_untile(api, gpu_ready):
     torch = gpu_ready
     hs = api.HostScene(golden_scene("cornell64"))
