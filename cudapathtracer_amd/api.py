@@ -87,6 +87,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise PtError("%s is missing: build it with `make -C cudapathtracer_amd/csrc` (or __graft_entry__.build()); "
                       "this package has no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: torch ships its own libamdhip64 / libhsa-runtime64, and whichever of
+    # two copies initialises second finds "no ROCm-capable device". With torch loaded first, libptamd's
+    # DT_NEEDED libamdhip64.so.7 resolves to the copy already in the process. (A C/C++ host that does
+    # not use torch links the system ROCm only and has no such issue.)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, u64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_float
     L.pt_api_version.restype = i32
@@ -114,6 +119,9 @@ def lib():
     L.pt_probe_bsdf_sample.argtypes = [vp, i32, vp, vp, vp, f32, f32, u64, vp, vp]
     L.pt_probe_bsdf_eval.argtypes = [vp, i32, vp, vp, vp, f32, f32, vp]
     L.novum_scene_load.restype = vp; L.novum_scene_load.argtypes = [C.c_char_p, C.c_char_p, i32]
+    L.novum_scene_load_ex.restype = vp; L.novum_scene_load_ex.argtypes = [C.c_char_p, C.c_char_p, i32, i32]
+    L.pt_bvh_build_device.argtypes = [vp, i32, vp, i32, i32, i32, vp, i32, vp, vp]
+    L.novum_bvh_build_host.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, vp]
     L.novum_scene_free.argtypes = [vp]
     L.novum_scene_info.argtypes = [vp, vp]
     L.novum_scene_desc.argtypes = [vp, C.POINTER(SceneDesc)]
@@ -179,6 +187,32 @@ def init_render(config_path, render_number=0, base_dir=None, bmp_path=None, prev
     return out
 
 
+BUILD_STATS = np.dtype([("n_nodes", "i4"), ("largest_leaf", "i4"), ("backups", "i4"), ("depth", "i4"), ("sort_fallbacks", "i4"),
+                        ("levels", "i4"), ("device_ms", "f4"), ("total_ms", "f4")])
+
+
+def build_bvh(points, mesh, max_leaf_size, where="device"):
+    """buildBVH (main.cu:20-233) on raw arrays in the reference's layouts: `points` float4[n] bytes,
+    `mesh` Triangle (80 B)[n] bytes. where="device": pt_bvh_build_device (reference-tree
+    mode); where="host": the kept host builder. Returns (nodes uint8[48*n_nodes], indices int32[n], stats dict)."""
+    pts = np.ascontiguousarray(points).view(np.uint8).reshape(-1)
+    m = np.ascontiguousarray(mesh).view(np.uint8).reshape(-1)
+    n = m.size // 80
+    cap = max(2 * n - 1, 1)
+    nodes = np.zeros(cap * 48, np.uint8)
+    idx = np.zeros(max(n, 1), np.int32)
+    st = np.zeros(1, BUILD_STATS)
+    if where == "device":
+        k = lib().pt_bvh_build_device(_p(pts), pts.size // 16, _p(m), n, int(max_leaf_size), 0, _p(nodes), cap, _p(idx), _p(st))
+        if k <= 0:
+            raise PtError("pt_bvh_build_device failed (%d): %s" % (k, lib().pt_last_error().decode(errors="replace")))
+    else:
+        k = lib().novum_bvh_build_host(_p(pts), pts.size // 16, _p(m), n, int(max_leaf_size), _p(nodes), cap, _p(idx), _p(st))
+        if k <= 0:
+            raise PtError("novum_bvh_build_host failed (%d)" % k)
+    return nodes[:k * 48].copy(), idx[:n], {f: st[0][f].item() for f in BUILD_STATS.names}
+
+
 class HostScene:
     """What the kept scene loader produces (novum_scene_load): host arrays in the reference's data model."""
 
@@ -187,10 +221,12 @@ class HostScene:
                "indices": ("bvh_indices", "n_triangles", 4), "materials": ("materials", "n_materials", 176),
                "textures": ("textures", "n_texels", 16)}
 
-    def __init__(self, config_path, base_dir=None, render_number=0):
-        self.h = lib().novum_scene_load(config_path.encode(), base_dir.encode() if base_dir else None, render_number)
+    def __init__(self, config_path, base_dir=None, render_number=0, bvh_builder="host"):
+        """bvh_builder: "host" (the reference's buildBVH on the CPU) or "device" (pt_bvh_build_device; same arrays)."""
+        self.h = lib().novum_scene_load_ex(config_path.encode(), base_dir.encode() if base_dir else None, render_number,
+                                           {"host": 0, "device": 1}[bvh_builder])
         if not self.h:
-            raise PtError("novum_scene_load failed for " + config_path)
+            raise PtError("novum_scene_load failed for %s: %s" % (config_path, lib().pt_last_error().decode(errors="replace")))
         info = np.zeros(16, np.int32)
         lib().novum_scene_info(self.h, _p(info))
         self.info = dict(zip(INFO_KEYS, (int(v) for v in info)))

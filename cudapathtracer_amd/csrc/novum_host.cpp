@@ -12,6 +12,7 @@
 // builder is a full sort by (centroid, index); parseVec3's .w is 0.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -294,8 +295,12 @@ struct Builder {
     novum_scene& S;
     std::vector<pt_float4> cen, lo, hi;
     int leafMax;
-    static pt_float4 vmin(const pt_float4& a, const pt_float4& b) { return P4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
-    static pt_float4 vmax(const pt_float4& a, const pt_float4& b) { return P4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+    // fminf / fmaxf with the one freedom IEEE leaves (which zero of -0, +0) fixed as -0 < +0, so that a
+    // union over a set does not depend on the order it is taken in (the device builder reduces in parallel).
+    static float lo1(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == 0.0f && b == 0.0f) return std::signbit(a) ? a : b; return a < b ? a : b; }
+    static float hi1(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == 0.0f && b == 0.0f) return std::signbit(a) ? b : a; return a > b ? a : b; }
+    static pt_float4 vmin(const pt_float4& a, const pt_float4& b) { return P4(lo1(a.x, b.x), lo1(a.y, b.y), lo1(a.z, b.z)); }
+    static pt_float4 vmax(const pt_float4& a, const pt_float4& b) { return P4(hi1(a.x, b.x), hi1(a.y, b.y), hi1(a.z, b.z)); }
     static float area(const pt_float4& mn, const pt_float4& mx) { float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z; return 2.0f * (dx * dy + dx * dz + dy * dz); }
 
     void prims() {                                               // computeInfoForBVH, main.cu:20-47
@@ -459,7 +464,7 @@ float aces(float c) { return clamp01((c * (2.51f * c + 0.03f)) / (c * (2.43f * c
 
 extern "C" {
 
-novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number) {
+novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, int render_number, int bvh_builder) {
     if (!config_path) return nullptr;
     novum_scene* S = new novum_scene();
     if (!parse_config(config_path, S->cfg)) { delete S; return nullptr; }
@@ -490,11 +495,54 @@ novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int
     if (S->mesh.empty()) { fprintf(stderr, "Error: No triangles loaded.\n"); delete S; return nullptr; }
     S->indices.resize(S->mesh.size());
     for (size_t i = 0; i < S->mesh.size(); i++) S->indices[i] = (int32_t)i;
-    Builder b{*S, {}, {}, {}, c.leafSize};
-    b.prims();
-    b.build();
+    if (bvh_builder == NOVUM_BVH_DEVICE) {                        // f-4: same tree, built on the GPU
+        S->bvh.resize(2 * S->mesh.size());
+        pt_bvh_build_stats st{};
+        int k = pt_bvh_build_device(S->points.data(), (int)S->points.size(), S->mesh.data(), (int)S->mesh.size(), c.leafSize,
+                                    PT_BVH_REFERENCE_TREE, S->bvh.data(), (int)S->bvh.size(), S->indices.data(), &st);
+        if (k <= 0) { fprintf(stderr, "novum_scene_load: %s\n", pt_last_error()); delete S; return nullptr; }
+        S->bvh.resize(k);
+        S->largestLeaf = st.largest_leaf; S->backups = st.backups;
+    } else {
+        Builder b{*S, {}, {}, {}, c.leafSize};
+        b.prims();
+        b.build();
+    }
     S->treeDepth = tree_depth(S->bvh);
     return S;
+}
+
+novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number) {
+    return novum_scene_load_ex(config_path, base_dir, render_number, NOVUM_BVH_HOST);
+}
+
+int novum_bvh_build_host(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
+                         int max_leaf_size, pt_bvh_node* nodes_out, int nodes_capacity, int32_t* indices_out,
+                         pt_bvh_build_stats* stats) {
+    if (!positions || !triangles || !nodes_out || !indices_out || n_triangles <= 0 || n_positions <= 0) return -1;
+    for (int i = 0; i < n_triangles; i++) {
+        const pt_triangle& t = triangles[i];
+        if (t.aInd < 0 || t.aInd >= n_positions || t.bInd < 0 || t.bInd >= n_positions || t.cInd < 0 || t.cInd >= n_positions) return -1;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    novum_scene S;
+    S.points.assign(positions, positions + n_positions);
+    S.mesh.assign(triangles, triangles + n_triangles);
+    S.indices.resize(n_triangles);
+    for (int i = 0; i < n_triangles; i++) S.indices[i] = i;
+    Builder b{S, {}, {}, {}, max_leaf_size};
+    b.prims();
+    b.build();
+    if ((int)S.bvh.size() > nodes_capacity) return -1;
+    std::memcpy(nodes_out, S.bvh.data(), S.bvh.size() * sizeof(pt_bvh_node));
+    std::memcpy(indices_out, S.indices.data(), sizeof(int32_t) * (size_t)n_triangles);
+    if (stats) {
+        *stats = pt_bvh_build_stats{};
+        stats->n_nodes = (int)S.bvh.size(); stats->largest_leaf = S.largestLeaf; stats->backups = S.backups;
+        stats->depth = stats->levels = tree_depth(S.bvh);
+        stats->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return (int)S.bvh.size();
 }
 
 void novum_scene_free(novum_scene* s) { delete s; }

@@ -70,6 +70,8 @@ struct pt_scene {
 
 extern "C" {
 
+int pt_fail_(int code, const char* msg) { g_err = msg; return code; }     // for the other translation units
+
 int pt_api_version(void) { return PT_API_VERSION; }
 const char* pt_last_error(void) { return g_err.c_str(); }
 

@@ -1,0 +1,648 @@
+// pt_bvh_build.hip — SURVEY.md §8 f-4: the reference's binned-SAH BVH build (computeInfoForBVH +
+// buildBVH + SAH + partitionPrimitives, main.cu:20-233; call site main.cu:524-530) on the GPU.
+//
+// "Reference-tree" mode: the output (pre-order BVHnode array + BVHindices permutation, largest
+// leaf, backup count) is BYTE-IDENTICAL to the host builder's (novum_host.cpp: Builder; tests/
+// test_bvh_build.py holds both to the CPU restatement). The reference recursion is depth-first and
+// sequential; here every tree LEVEL is one batch of data-parallel passes over the primitive
+// positions (a node's primitives are a contiguous range of the index array, as in the reference):
+//
+//   classify   per node      bounds -> node record; leaf test (main.cu:153); split axis (:161-168)
+//   bin        per position  12 buckets over the node bounds on the axis (:76-85); unions and counts
+//                            through order-independent atomics on order-preserving integer keys
+//   sah        per node      the reference's cost loop incl. its right-count quirk (:90-117)
+//   (sort)     rare          median fallback (:119-128) = total-order sort of the node's range
+//   flag+scan  per position  centroid < splitPos (:185-188) and an exclusive prefix sum over ALL
+//                            positions; numLeft of a node = S[end] - S[start]
+//   (mean)     rare          centroid-mean retry (:192-202): a float sum in the reference's order,
+//                            one wave per node, lanes fetch, the adds stay sequential
+//   partition  per position  partitionPrimitives (:49-62) is a Lomuto loop; its result has a closed
+//                            form: the k-th element below splitPos lands on start+k, and an element
+//                            not below splitPos standing on slot p is moved, whenever p - start <
+//                            numLeft, to the original position of the (p-start)-th element below
+//                            splitPos — followed until p - start >= numLeft. The same pass unions
+//                            the primitive's box into its child's bounds (min/max are exact, so the
+//                            union order does not matter).
+//
+// Nodes are numbered breadth-first while building; two sweeps over the levels (subtree sizes up,
+// pre-order index down) give the reference's depth-first numbering. All float arithmetic is
+// written as the reference writes it and compiled with -ffp-contract=off.
+// min/max over boxes use the total order of the integer keys, which is fminf/fmaxf on the finite
+// values the builder accepts and puts -0 below +0 (the host builder does the same).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/pt_api.h"
+
+extern "C" int pt_fail_(int code, const char* msg);
+
+namespace {
+
+constexpr int NB = 12;
+constexpr int kBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kBlock * kScanItems;
+
+enum : int { ST_LEAF = 1, ST_SPLITTING = 2, ST_SORT = 3, ST_OK = 4, ST_REDO = 5 };
+
+struct WorkNode {                 // 64 B, one per node of the level being built
+    int start, end, out, axis;
+    unsigned lo[3], hi[3];        // bounds as order-preserving keys (atomicMin / atomicMax targets)
+    float split;
+    int numLeft, state, child, bin;
+    int pad;
+};
+struct Bins { unsigned lo[NB][3], hi[NB][3]; int cnt[NB]; };
+struct OutNode { float lo[3], hi[3]; int left, right, first, count, size, pre; };
+struct Ctl { int nextCount, outCount, binCount, anySort, anyRedo, redoCount, largestLeaf, backups, sortFallbacks, bad; };
+
+__host__ __device__ inline unsigned fkey(float f) {
+    unsigned u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float funkey(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+__device__ inline unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ inline unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ inline unsigned wave_min(unsigned v) {
+    for (int o = 32; o; o >>= 1) v = umin_(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ inline unsigned wave_max(unsigned v) {
+    for (int o = 32; o; o >>= 1) v = umax_(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ inline int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ inline float comp3(const float* cx, const float* cy, const float* cz, int axis, int id) {
+    return axis == 0 ? cx[id] : (axis == 1 ? cy[id] : cz[id]);
+}
+
+struct Arrays {
+    const pt_float4* pos; int nPos;
+    const pt_triangle* mesh; int n;
+    float *cx, *cy, *cz;
+    float4 *lo, *hi;
+    int *idxA, *idxB, *nodeA, *nodeB, *tmp, *S, *g, *blockSum, *redoList;
+    unsigned char* F;
+    WorkNode *workA, *workB;
+    Bins* bins;
+    OutNode* out;
+    pt_bvh_node* fin;
+    Ctl* ctl;
+};
+
+// Union of a box into a node's key bounds. When every active lane of the wave targets the same
+// node (the top levels) the wave reduces first and issues six atomics instead of 6 x 64.
+__device__ inline void union_into(bool act, int target, unsigned* lo0, unsigned* hi0, size_t strideBytes,
+                                  const unsigned kl[3], const unsigned kh[3]) {
+    unsigned long long am = __ballot(act);
+    if (am == 0) return;
+    unsigned long long rem = am;
+    // at most two distinct targets are reduced wave-wide; anything beyond falls back to per-lane atomics
+    for (int round = 0; round < 2 && rem; round++) {
+        int l = __ffsll((unsigned long long)rem) - 1;
+        int t0 = __shfl(target, l);
+        bool sel = act && target == t0;
+        unsigned long long sm = __ballot(sel);
+        if (__popcll(sm) >= 8) {
+            unsigned r[6];
+            for (int k = 0; k < 3; k++) { r[k] = wave_min(sel ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(sel ? kh[k] : 0u); }
+            if (lane_id() == l) {
+                unsigned* L = (unsigned*)((char*)lo0 + (size_t)t0 * strideBytes);
+                unsigned* H = (unsigned*)((char*)hi0 + (size_t)t0 * strideBytes);
+                for (int k = 0; k < 3; k++) { atomicMin(L + k, r[k]); atomicMax(H + k, r[3 + k]); }
+            }
+            act = act && !sel;
+        }
+        rem &= ~sm;
+    }
+    if (act) {
+        unsigned* L = (unsigned*)((char*)lo0 + (size_t)target * strideBytes);
+        unsigned* H = (unsigned*)((char*)hi0 + (size_t)target * strideBytes);
+        for (int k = 0; k < 3; k++) { atomicMin(L + k, kl[k]); atomicMax(H + k, kh[k]); }
+    }
+}
+
+// computeInfoForBVH, main.cu:20-47, plus the root's bounds and the identity permutation (:503-504).
+__global__ void k_prims(Arrays A) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = i < A.n;
+    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+    if (ok) {
+        pt_triangle t = A.mesh[i];
+        int ia = t.aInd, ib = t.bInd, ic = t.cInd;
+        if ((unsigned)ia >= (unsigned)A.nPos || (unsigned)ib >= (unsigned)A.nPos || (unsigned)ic >= (unsigned)A.nPos) { A.ctl->bad = 1; ia = ib = ic = 0; }
+        pt_float4 a = A.pos[ia], b = A.pos[ib], c = A.pos[ic];
+        float mx = fminf(fminf(a.x, b.x), c.x) - 0.000001f, my = fminf(fminf(a.y, b.y), c.y) - 0.000001f, mz = fminf(fminf(a.z, b.z), c.z) - 0.000001f;
+        float Mx = fmaxf(fmaxf(a.x, b.x), c.x) + 0.000001f, My = fmaxf(fmaxf(a.y, b.y), c.y) + 0.000001f, Mz = fmaxf(fmaxf(a.z, b.z), c.z) + 0.000001f;
+        A.cx[i] = (a.x + b.x + c.x) / 3.0f; A.cy[i] = (a.y + b.y + c.y) / 3.0f; A.cz[i] = (a.z + b.z + c.z) / 3.0f;
+        A.lo[i] = make_float4(mx, my, mz, 0.0f); A.hi[i] = make_float4(Mx, My, Mz, 0.0f);
+        // non-finite geometry has no defined tree in the reference either (NaN compares); refuse it
+        float big = fmaxf(fmaxf(fabsf(mx), fabsf(my)), fmaxf(fmaxf(fabsf(mz), fabsf(Mx)), fmaxf(fabsf(My), fabsf(Mz))));
+        float any = ((a.x + a.y + a.z) + (b.x + b.y + b.z)) + (c.x + c.y + c.z);          // NaN anywhere -> NaN
+        if (!(big <= 1e37f) || any != any) A.ctl->bad = 2;
+        A.idxA[i] = i; A.nodeA[i] = 0; A.nodeB[i] = -1;
+        kl[0] = fkey(mx); kl[1] = fkey(my); kl[2] = fkey(mz); kh[0] = fkey(Mx); kh[1] = fkey(My); kh[2] = fkey(Mz);
+    }
+    union_into(ok, 0, A.workA[0].lo, A.workA[0].hi, sizeof(WorkNode), kl, kh);
+}
+
+// Node record + leaf test + axis choice, main.cu:139-168.
+__global__ void k_classify(Arrays A, WorkNode* work, int W, int leafMax) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    WorkNode nd = work[w];
+    OutNode& o = A.out[nd.out];
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; k++) { mn[k] = funkey(nd.lo[k]); mx[k] = funkey(nd.hi[k]); o.lo[k] = mn[k]; o.hi[k] = mx[k]; }
+    int n = nd.end - nd.start;
+    if (n <= leafMax) {
+        o.first = nd.start; o.count = n; o.left = o.right = -1;
+        work[w].state = ST_LEAF;
+        atomicMax(&A.ctl->largestLeaf, n);
+        return;
+    }
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    int axis = (dy > dx && dy > dz) ? 1 : ((dz > dx && dz > dy) ? 2 : 0);
+    int b = atomicAdd(&A.ctl->binCount, 1);
+    work[w].axis = axis; work[w].state = ST_SPLITTING; work[w].bin = b;
+    Bins& B = A.bins[b];
+    const unsigned kmax = fkey(FLT_MAX), kmin = fkey(-FLT_MAX);      // main.cu:71-75
+    for (int i = 0; i < NB; i++) { for (int k = 0; k < 3; k++) { B.lo[i][k] = kmax; B.hi[i][k] = kmin; } B.cnt[i] = 0; }
+}
+
+// Bucket fill, main.cu:76-85.
+__global__ void k_bin(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = p < A.n ? nodeOf[p] : -1;
+    bool act = w >= 0 && work[w].state == ST_SPLITTING;
+    int b = 0, bin = 0;
+    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+    if (act) {
+        const WorkNode& nd = work[w];
+        int id = idx[p], axis = nd.axis;
+        bin = nd.bin;
+        float a0 = funkey(nd.lo[axis]), ext = funkey(nd.hi[axis]) - a0;
+        float q = NB * (comp3(A.cx, A.cy, A.cz, axis, id) - a0) / ext;
+        b = (q == q && fabsf(q) < 1e9f) ? (int)q : 0;               // int(NaN/inf) is UB in the reference; defined 0
+        b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+        float4 l = A.lo[id], h = A.hi[id];
+        kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
+    }
+    unsigned long long am = __ballot(act);
+    if (am == 0) return;
+    int lead = __ffsll((unsigned long long)am) - 1;
+    bool uniform = __all(!act || bin == __shfl(bin, lead)) != 0;
+    if (uniform) {
+        int bin0 = __shfl(bin, lead);
+        Bins& B = A.bins[bin0];
+        unsigned long long rem = am;
+        while (rem) {
+            int l = __ffsll((unsigned long long)rem) - 1;
+            int b0 = __shfl(b, l);
+            bool sel = act && b == b0;
+            unsigned long long sm = __ballot(sel);
+            unsigned r[6];
+            for (int k = 0; k < 3; k++) { r[k] = wave_min(sel ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(sel ? kh[k] : 0u); }
+            if (lane_id() == l) {
+                for (int k = 0; k < 3; k++) { atomicMin(&B.lo[b0][k], r[k]); atomicMax(&B.hi[b0][k], r[3 + k]); }
+                atomicAdd(&B.cnt[b0], (int)__popcll(sm));
+            }
+            rem &= ~sm;
+        }
+    } else if (act) {
+        Bins& B = A.bins[bin];
+        for (int k = 0; k < 3; k++) { atomicMin(&B.lo[b][k], kl[k]); atomicMax(&B.hi[b][k], kh[k]); }
+        atomicAdd(&B.cnt[b], 1);
+    }
+}
+
+__device__ inline float area_keys(const unsigned lo[3], const unsigned hi[3]) {   // surfaceArea, util.cuh:225-231
+    float dx = funkey(hi[0]) - funkey(lo[0]), dy = funkey(hi[1]) - funkey(lo[1]), dz = funkey(hi[2]) - funkey(lo[2]);
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+
+// Cost sweep, main.cu:87-131. Right side: bucket i is counted twice (:102-109), kept.
+__global__ void k_sah(Arrays A, WorkNode* work, int W) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    if (work[w].state != ST_SPLITTING) return;
+    WorkNode nd = work[w];
+    const Bins& B = A.bins[nd.bin];
+    unsigned rlo[NB][3], rhi[NB][3]; int rc[NB];
+    int suffix = B.cnt[NB - 1];
+    for (int k = 0; k < 3; k++) { rlo[NB - 1][k] = B.lo[NB - 1][k]; rhi[NB - 1][k] = B.hi[NB - 1][k]; }
+    rc[NB - 1] = B.cnt[NB - 1] + suffix;
+    for (int i = NB - 2; i >= 1; i--) {
+        for (int k = 0; k < 3; k++) { rlo[i][k] = umin_(B.lo[i][k], rlo[i + 1][k]); rhi[i][k] = umax_(B.hi[i][k], rhi[i + 1][k]); }
+        suffix += B.cnt[i];
+        rc[i] = B.cnt[i] + suffix;
+    }
+    const float whole = area_keys(nd.lo, nd.hi);
+    unsigned llo[3], lhi[3]; int lc = B.cnt[0];
+    for (int k = 0; k < 3; k++) { llo[k] = B.lo[0][k]; lhi[k] = B.hi[0][k]; }
+    float best = FLT_MAX; int bestI = -1;
+    for (int i = 1; i < NB; i++) {
+        float cost = 1.0f + (lc * area_keys(llo, lhi) + rc[i] * area_keys(rlo[i], rhi[i])) / whole;
+        if (cost < best && (lc > 0 && rc[i] > 0)) { best = cost; bestI = i; }
+        for (int k = 0; k < 3; k++) { llo[k] = umin_(llo[k], B.lo[i][k]); lhi[k] = umax_(lhi[k], B.hi[i][k]); }
+        lc += B.cnt[i];
+    }
+    if (bestI < 0) {
+        work[w].state = ST_SORT;
+        A.ctl->anySort = 1;
+        atomicAdd(&A.ctl->sortFallbacks, 1);
+    } else {
+        float a0 = funkey(nd.lo[nd.axis]), ext = funkey(nd.hi[nd.axis]) - a0;
+        work[w].split = a0 + ext * (float(bestI) / float(NB));
+    }
+}
+
+// Median fallback, main.cu:119-128: nth_element's permutation is STL-specific; SURVEY App. D fixes
+// it as a sort by (centroid[axis], index). Rank by counting — rare and small in practice.
+__global__ void k_sort_rank(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf) {
+    if (!A.ctl->anySort) return;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n) return;
+    int w = nodeOf[p];
+    if (w < 0 || work[w].state != ST_SORT) return;
+    const WorkNode& nd = work[w];
+    int me = idx[p], axis = nd.axis, rank = 0;
+    float ca = comp3(A.cx, A.cy, A.cz, axis, me);
+    for (int j = nd.start; j < nd.end; j++) {
+        int o = idx[j];
+        float cb = comp3(A.cx, A.cy, A.cz, axis, o);
+        rank += (cb < ca || (!(ca < cb) && o < me)) ? 1 : 0;
+    }
+    A.tmp[nd.start + rank] = me;
+}
+__global__ void k_sort_apply(Arrays A, WorkNode* work, int* idx, const int* nodeOf) {
+    if (!A.ctl->anySort) return;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n) return;
+    int w = nodeOf[p];
+    if (w < 0 || work[w].state != ST_SORT) return;
+    int id = A.tmp[p];
+    idx[p] = id;
+    if (p == (work[w].start + work[w].end) / 2) work[w].split = comp3(A.cx, A.cy, A.cz, work[w].axis, id);
+}
+
+// centroid[axis] < splitPos, main.cu:185-188 (first pass) and :206-209 (after the mean retry).
+__global__ void k_flag(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf, int redoOnly) {
+    if (redoOnly && !A.ctl->anyRedo) return;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n) return;
+    int w = nodeOf[p];
+    unsigned char f = 0;
+    if (w >= 0) {
+        int st = work[w].state;
+        if (redoOnly) { if (st != ST_REDO) return; }
+        else if (st != ST_SPLITTING && st != ST_SORT) st = 0;
+        if (st) f = comp3(A.cx, A.cy, A.cz, work[w].axis, idx[p]) < work[w].split ? 1 : 0;
+    } else if (redoOnly) return;
+    A.F[p] = f;
+}
+
+// ---- exclusive prefix sum of F over all positions: S[0..n], S[n] = total ------------------------
+__device__ inline int block_exclusive(int v, int* total) {
+    __shared__ int waveSum[kBlock / 64];
+    int lane = lane_id(), wv = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) waveSum[wv] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < kBlock / 64; i++) { int s = waveSum[i]; if (i < wv) off += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+__device__ inline int load_flags(const unsigned char* F, int n, int base, int f[kScanItems]) {
+    int sum = 0;
+    if (base + kScanItems <= n) {
+        unsigned long long v = *(const unsigned long long*)(F + base);
+        for (int j = 0; j < kScanItems; j++) { f[j] = (int)((v >> (8 * j)) & 0xff); sum += f[j]; }
+    } else {
+        for (int j = 0; j < kScanItems; j++) { f[j] = base + j < n ? F[base + j] : 0; sum += f[j]; }
+    }
+    return sum;
+}
+__global__ void k_scan1(Arrays A, int gated) {
+    if (gated && !A.ctl->anyRedo) return;
+    int f[kScanItems];
+    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int s = load_flags(A.F, A.n, base, f), tot;
+    block_exclusive(s, &tot);
+    if (threadIdx.x == 0) A.blockSum[blockIdx.x] = tot;
+}
+__global__ void k_scan2(Arrays A, int M, int gated) {
+    if (gated && !A.ctl->anyRedo) return;
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < M; base += kBlock) {
+        int i = base + threadIdx.x;
+        int v = i < M ? A.blockSum[i] : 0, tot;
+        int ex = block_exclusive(v, &tot);
+        int c = carry;
+        if (i < M) A.blockSum[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.S[A.n] = carry;
+}
+__global__ void k_scan3(Arrays A, int gated) {
+    if (gated && !A.ctl->anyRedo) return;
+    int f[kScanItems];
+    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int s = load_flags(A.F, A.n, base, f), tot;
+    int run = A.blockSum[blockIdx.x] + block_exclusive(s, &tot);
+    for (int j = 0; j < kScanItems; j++) { if (base + j < A.n) A.S[base + j] = run; run += f[j]; }
+}
+
+// numLeft test, main.cu:189-190 (pass 0) and :210-221 (pass 1: forced, possibly oversize, leaf).
+__global__ void k_check(Arrays A, WorkNode* work, int W, int pass) {
+    if (pass == 1 && !A.ctl->anyRedo) return;
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    int st = work[w].state;
+    if (pass == 0 ? (st != ST_SPLITTING && st != ST_SORT) : st != ST_REDO) return;
+    int s = work[w].start, e = work[w].end, n = e - s;
+    int nl = A.S[e] - A.S[s];
+    if (nl > 0 && nl < n - 1) { work[w].state = ST_OK; work[w].numLeft = nl; return; }
+    if (pass == 0) {
+        work[w].state = ST_REDO;
+        A.redoList[atomicAdd(&A.ctl->redoCount, 1)] = w;
+        A.ctl->anyRedo = 1;
+        atomicAdd(&A.ctl->backups, 1);
+    } else {
+        OutNode& o = A.out[work[w].out];
+        o.first = s; o.count = n; o.left = o.right = -1;
+        work[w].state = ST_LEAF;
+        atomicMax(&A.ctl->largestLeaf, n);
+    }
+}
+
+// Centroid-mean retry, main.cu:192-202: `sum += c` in index order, then sum / primCount.
+__global__ void k_mean(Arrays A, WorkNode* work, const int* idx) {
+    if (!A.ctl->anyRedo) return;
+    int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6, lane = lane_id();
+    int count = A.ctl->redoCount;
+    for (int r = wave; r < count; r += nWaves) {
+        int w = A.redoList[r];
+        int s = work[w].start, e = work[w].end, axis = work[w].axis;
+        float sum = 0.0f;
+        for (int base = s; base < e; base += 64) {
+            int p = base + lane;
+            float v = p < e ? comp3(A.cx, A.cy, A.cz, axis, idx[p]) : 0.0f;
+            int cnt = e - base < 64 ? e - base : 64;
+            for (int k = 0; k < cnt; k++) sum += __shfl(v, k);
+        }
+        if (lane == 0) work[w].split = sum / (e - s);
+    }
+}
+
+// Children of the nodes that split, main.cu:226-227 (numbered later).
+__global__ void k_alloc(Arrays A, WorkNode* work, WorkNode* next, int W) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    if (work[w].state != ST_OK) return;
+    int c = atomicAdd(&A.ctl->nextCount, 2), o = atomicAdd(&A.ctl->outCount, 2);
+    int s = work[w].start, e = work[w].end, mid = s + work[w].numLeft;
+    work[w].child = c;
+    OutNode& on = A.out[work[w].out];
+    on.left = o; on.right = o + 1; on.first = -1; on.count = 0;
+    for (int k = 0; k < 2; k++) {
+        WorkNode& ch = next[c + k];
+        ch.start = k ? mid : s; ch.end = k ? e : mid; ch.out = o + k; ch.axis = 0;
+        for (int j = 0; j < 3; j++) { ch.lo[j] = 0xffffffffu; ch.hi[j] = 0u; }
+        ch.split = 0.0f; ch.numLeft = 0; ch.state = 0; ch.child = -1; ch.bin = -1;
+    }
+}
+
+// g[start + k] = position of the node's k-th element below splitPos.
+__global__ void k_goodpos(Arrays A, const WorkNode* work, const int* nodeOf) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n) return;
+    int w = nodeOf[p];
+    if (w < 0 || work[w].state != ST_OK || !A.F[p]) return;
+    int s = work[w].start;
+    A.g[s + (A.S[p] - A.S[s])] = p;
+}
+
+// partitionPrimitives, main.cu:49-62, in closed form (header); child bounds, main.cu:139-148.
+__global__ void k_scatter(Arrays A, const WorkNode* work, WorkNode* next, const int* idx, int* idxOut, int* nodeOf, int* nodeOut) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int w = p < A.n ? nodeOf[p] : -1;
+    int st = w >= 0 ? work[w].state : 0;
+    bool act = st == ST_OK;
+    int child = 0;
+    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+    if (st == ST_LEAF) { idxOut[p] = idx[p]; nodeOut[p] = -1; nodeOf[p] = -1; }
+    if (act) {
+        const WorkNode& nd = work[w];
+        int s = nd.start, nl = nd.numLeft, id = idx[p], dest;
+        if (A.F[p]) dest = s + (A.S[p] - A.S[s]);
+        else {
+            dest = p;
+            while (dest - s < nl) {
+                int to = A.g[dest];
+                if (to <= dest) { A.ctl->bad = 3; break; }          // cannot happen (header); never spin on the GPU
+                dest = to;
+            }
+        }
+        child = nd.child + (dest < s + nl ? 0 : 1);
+        idxOut[dest] = id; nodeOut[dest] = child;
+        float4 l = A.lo[id], h = A.hi[id];
+        kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
+    }
+    union_into(act, child, next[0].lo, next[0].hi, sizeof(WorkNode), kl, kh);
+}
+
+__global__ void k_next_level(Arrays A) {
+    Ctl& c = *A.ctl;
+    c.nextCount = 0; c.binCount = 0; c.anySort = 0; c.anyRedo = 0; c.redoCount = 0;
+}
+
+// ---- breadth-first -> the reference's depth-first numbering (nodes.size() at push, main.cu:137) ----
+__global__ void k_size(Arrays A, int a, int b) {
+    int o = a + blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= b) return;
+    OutNode& n = A.out[o];
+    n.size = n.count > 0 ? 1 : 1 + A.out[n.left].size + A.out[n.right].size;
+}
+__global__ void k_pre(Arrays A, int a, int b) {
+    int o = a + blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= b) return;
+    const OutNode& n = A.out[o];
+    if (n.count > 0) return;
+    A.out[n.left].pre = n.pre + 1;
+    A.out[n.right].pre = n.pre + 1 + A.out[n.left].size;
+}
+__global__ void k_emit(Arrays A, int total) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const OutNode& n = A.out[o];
+    pt_bvh_node f;
+    f.aabbMIN = pt_float4{n.lo[0], n.lo[1], n.lo[2], 0.0f};
+    f.aabbMAX = pt_float4{n.hi[0], n.hi[1], n.hi[2], 0.0f};
+    if (n.count > 0) { f.left = f.right = -1; f.first = n.first; f.primCount = n.count; }
+    else { f.left = A.out[n.left].pre; f.right = A.out[n.right].pre; f.first = -1; f.primCount = 0; }
+    A.fin[n.pre] = f;
+}
+
+inline int blocks(long long n, int per = kBlock) { return (int)std::max<long long>(1, (n + per - 1) / per); }
+
+struct Carver {
+    char* base = nullptr; size_t off = 0;
+    template <class T> T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+void carve(Carver& c, Arrays& A, int n, int nPos, int maxBins) {
+    A.pos = c.take<pt_float4>(nPos); A.mesh = c.take<pt_triangle>(n);
+    A.cx = c.take<float>(n); A.cy = c.take<float>(n); A.cz = c.take<float>(n);
+    A.lo = c.take<float4>(n); A.hi = c.take<float4>(n);
+    A.idxA = c.take<int>(n); A.idxB = c.take<int>(n); A.nodeA = c.take<int>(n); A.nodeB = c.take<int>(n);
+    A.tmp = c.take<int>(n); A.S = c.take<int>((size_t)n + 1); A.g = c.take<int>(n);
+    A.blockSum = c.take<int>((size_t)blocks(n, kScanTile) + 1);
+    A.redoList = c.take<int>(maxBins);
+    A.F = c.take<unsigned char>((size_t)n + 16);
+    A.workA = c.take<WorkNode>((size_t)n + 2); A.workB = c.take<WorkNode>((size_t)n + 2);
+    A.bins = c.take<Bins>(maxBins);
+    A.out = c.take<OutNode>(2 * (size_t)n); A.fin = c.take<pt_bvh_node>(2 * (size_t)n);
+    A.ctl = c.take<Ctl>(1);
+}
+
+#define BVH_HIP(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char m_[384];                                                                         \
+            snprintf(m_, sizeof(m_), "pt_bvh_build_device: %s failed: %s", #expr, hipGetErrorString(e_)); \
+            if (pool) (void)hipFree(pool);                                                        \
+            return pt_fail_(-2, m_);                                                              \
+        }                                                                                         \
+    } while (0)
+
+}  // namespace
+
+extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
+                                   int max_leaf_size, int mode, pt_bvh_node* nodes_out, int nodes_capacity,
+                                   int32_t* indices_out, pt_bvh_build_stats* stats) {
+    void* pool = nullptr;
+    if (mode != PT_BVH_REFERENCE_TREE) return pt_fail_(-3, "pt_bvh_build_device: only PT_BVH_REFERENCE_TREE (0) is built");
+    if (!positions || !triangles || !nodes_out || !indices_out) return pt_fail_(-1, "pt_bvh_build_device: null argument");
+    if (n_triangles <= 0 || n_positions <= 0) return pt_fail_(-1, "pt_bvh_build_device: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
+    if (n_triangles > (1 << 30)) return pt_fail_(-1, "pt_bvh_build_device: more than 2^30 triangles");
+    if (max_leaf_size < 0) return pt_fail_(-1, "pt_bvh_build_device: negative leaf size");
+    const int n = n_triangles;
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) {
+            char m[256];
+            snprintf(m, sizeof(m), "pt_bvh_build_device: no usable HIP device (%s); the device builder has no CPU fallback (novum_bvh_build_host is the host builder)", hipGetErrorString(e));
+            return pt_fail_(-2, m);
+        }
+    }
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int maxBins = n / (max_leaf_size + 1) + 2;
+    Arrays A{};
+    Carver sizer; carve(sizer, A, n, n_positions, maxBins);
+    BVH_HIP(hipMalloc(&pool, sizer.off + 256));
+    Carver real; real.base = (char*)pool; carve(real, A, n, n_positions, maxBins);
+    A.n = n; A.nPos = n_positions;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    BVH_HIP(hipEventCreate(&ev0)); BVH_HIP(hipEventCreate(&ev1));
+    BVH_HIP(hipMemcpy((void*)A.pos, positions, sizeof(pt_float4) * (size_t)n_positions, hipMemcpyHostToDevice));
+    BVH_HIP(hipMemcpy((void*)A.mesh, triangles, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice));
+    Ctl ctl{};
+    ctl.outCount = 1;
+    BVH_HIP(hipMemcpy(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
+    WorkNode root{};
+    root.start = 0; root.end = n; root.out = 0; root.child = -1; root.bin = -1;
+    for (int k = 0; k < 3; k++) { root.lo[k] = 0xffffffffu; root.hi[k] = 0u; }
+    BVH_HIP(hipMemcpy(A.workA, &root, sizeof(root), hipMemcpyHostToDevice));
+    const int gN = blocks(n), gScan = blocks(n, kScanTile);
+    BVH_HIP(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(k_prims, dim3(gN), dim3(kBlock), 0, st, A);
+
+    std::vector<int> levelOff{0, 1};      // out ids of level l are [levelOff[l], levelOff[l+1])
+    WorkNode *work = A.workA, *next = A.workB;
+    int *idx = A.idxA, *idxOut = A.idxB, *nodeOf = A.nodeA, *nodeOut = A.nodeB;
+    int W = 1, levels = 0;
+    while (W > 0) {
+        levels++;
+        if (levels > 4096) { (void)hipFree(pool); return pt_fail_(-4, "pt_bvh_build_device: more than 4096 levels"); }
+        const int gW = blocks(W);
+        hipLaunchKernelGGL(k_classify, dim3(gW), dim3(kBlock), 0, st, A, work, W, max_leaf_size);
+        hipLaunchKernelGGL(k_bin, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
+        hipLaunchKernelGGL(k_sah, dim3(gW), dim3(kBlock), 0, st, A, work, W);
+        hipLaunchKernelGGL(k_sort_rank, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
+        hipLaunchKernelGGL(k_sort_apply, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
+        for (int pass = 0; pass < 2; pass++) {
+            hipLaunchKernelGGL(k_flag, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf, pass);
+            hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, A, pass);
+            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, A, gScan, pass);
+            hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, A, pass);
+            hipLaunchKernelGGL(k_check, dim3(gW), dim3(kBlock), 0, st, A, work, W, pass);
+            if (pass == 0) hipLaunchKernelGGL(k_mean, dim3(std::min(gW, 2048)), dim3(kBlock), 0, st, A, work, idx);
+        }
+        hipLaunchKernelGGL(k_alloc, dim3(gW), dim3(kBlock), 0, st, A, work, next, W);
+        hipLaunchKernelGGL(k_goodpos, dim3(gN), dim3(kBlock), 0, st, A, work, nodeOf);
+        hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(kBlock), 0, st, A, work, next, idx, idxOut, nodeOf, nodeOut);
+        BVH_HIP(hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
+        BVH_HIP(hipStreamSynchronize(st));
+        if (ctl.bad) {
+            (void)hipFree(pool);
+            return pt_fail_(ctl.bad == 3 ? -4 : -1, ctl.bad == 1 ? "pt_bvh_build_device: a triangle's vertex index is out of range"
+                                          : ctl.bad == 2 ? "pt_bvh_build_device: non-finite vertex position (the reference's tree is undefined for it)"
+                                                         : "pt_bvh_build_device: internal error, partition chain did not advance");
+        }
+        W = ctl.nextCount;
+        levelOff.push_back(ctl.outCount);
+        hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, A);
+        std::swap(work, next); std::swap(idx, idxOut); std::swap(nodeOf, nodeOut);
+    }
+    // after the last level both index buffers agree on every position (leaves copy, splits scatter)
+    const int total = ctl.outCount;
+    if (total > nodes_capacity) { (void)hipFree(pool); return pt_fail_(-1, "pt_bvh_build_device: nodes_out too small (2*n_triangles-1 always suffices)"); }
+    const int L = (int)levelOff.size() - 1;
+    for (int l = L - 1; l >= 0; l--)
+        if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_size, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
+    BVH_HIP(hipMemsetAsync(&A.out[0].pre, 0, sizeof(int), st));
+    for (int l = 0; l < L; l++)
+        if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_pre, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
+    hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(kBlock), 0, st, A, total);
+    BVH_HIP(hipEventRecord(ev1, st));
+    BVH_HIP(hipMemcpy(nodes_out, A.fin, sizeof(pt_bvh_node) * (size_t)total, hipMemcpyDeviceToHost));
+    BVH_HIP(hipMemcpy(indices_out, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    float ms = 0.0f;
+    BVH_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    (void)hipFree(pool);
+    if (stats) {
+        stats->n_nodes = total; stats->largest_leaf = ctl.largestLeaf; stats->backups = ctl.backups; stats->depth = levels;
+        stats->sort_fallbacks = ctl.sortFallbacks; stats->levels = levels; stats->device_ms = ms;
+        stats->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return total;
+}

@@ -187,6 +187,27 @@ int pt_probe_bsdf_sample(pt_scene* scene, int n, const int32_t* material, const 
 int pt_probe_bsdf_eval(pt_scene* scene, int n, const int32_t* material, const float* wi3, const float* wo3,
                        float etaI, float etaT, float* out4);
 
+/* ---- f-4: BVH build on the device --------------------------------------------------------
+ * Replaces computeInfoForBVH + buildBVH (main.cu:20-233; call site main.cu:524-530: host vectors
+ * `bvhvec` / `indvec` out of `points` / `mesh`). PT_BVH_REFERENCE_TREE: the nodes (pre-order, as
+ * nodes.size() numbers them, main.cu:137) and the BVHindices permutation are byte-identical to the
+ * host builder's. Host pointers in and out; nodes_out needs room for 2*n_triangles-1 nodes.
+ * Returns the node count (> 0) or a negative error (pt_last_error()). No CPU fallback: without a
+ * HIP device it fails; novum_bvh_build_host is the kept host builder on the same arrays. */
+#define PT_BVH_REFERENCE_TREE 0
+typedef struct pt_bvh_build_stats {
+    int32_t n_nodes, largest_leaf, backups, depth;   /* what main.cu:537-538 prints */
+    int32_t sort_fallbacks, levels;
+    float device_ms;                                 /* HIP events around the build kernels */
+    float total_ms;                                  /* wall clock incl. allocation, upload, download */
+} pt_bvh_build_stats;
+int pt_bvh_build_device(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
+                        int max_leaf_size, int mode, pt_bvh_node* nodes_out, int nodes_capacity,
+                        int32_t* indices_out, pt_bvh_build_stats* stats);
+int novum_bvh_build_host(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
+                         int max_leaf_size, pt_bvh_node* nodes_out, int nodes_capacity,
+                         int32_t* indices_out, pt_bvh_build_stats* stats);
+
 /* ---- novum_*: the kept host side (scene loader / initRender) --------------------------- */
 typedef struct novum_scene novum_scene;    /* host arrays + RenderConfig + Camera */
 
@@ -194,6 +215,11 @@ typedef struct novum_scene novum_scene;    /* host arrays + RenderConfig + Camer
  * (main.cu:474-482, 936-1068) + computeInfoForBVH/buildBVH (main.cu:524-530) + camera
  * (main.cu:268-273). Mesh paths are resolved against base_dir (NULL = directory of the config). */
 novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number);
+/* Same, choosing who runs buildBVH: the host (as the reference does) or pt_bvh_build_device (f-4).
+ * Both give the same arrays. */
+#define NOVUM_BVH_HOST 0
+#define NOVUM_BVH_DEVICE 1
+novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, int render_number, int bvh_builder);
 void novum_scene_free(novum_scene* s);
 /* info[16]: width,height,spp,maxDepth,integrator,leafSize,nTris,nLights,nNodes,nPoints,nNormals,
  * nUvs,nMats,largestLeaf,backupCount,treeDepth */

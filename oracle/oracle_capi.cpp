@@ -45,6 +45,21 @@ void* oracle_scene_from_arrays(const void* points, int nPoints, const void* norm
     return s;
 }
 
+// The reference's builder alone (computeInfoForBVH + buildBVH, main.cu:20-233, call site :524-530)
+// on caller arrays: nodesOut has room for 2*nTris-1 BVHnodes, indicesOut for nTris ints.
+// stats[0..3] = node count, largest leaf, backup count, tree depth. Returns the node count.
+int oracle_build_bvh(const void* points, int nPoints, const void* mesh, int nTris, int maxLeafSize,
+                     void* nodesOut, int* indicesOut, int* stats) {
+    Scene sc;
+    sc.points.assign((const float4*)points, (const float4*)points + nPoints);
+    sc.mesh.assign((const Triangle*)mesh, (const Triangle*)mesh + nTris);
+    buildSceneBVH(sc, maxLeafSize);
+    std::memcpy(nodesOut, sc.bvh.data(), sc.bvh.size() * sizeof(BVHnode));
+    std::memcpy(indicesOut, sc.indices.data(), sc.indices.size() * sizeof(int));
+    if (stats) { stats[0] = (int)sc.bvh.size(); stats[1] = sc.largestLeaf; stats[2] = sc.backupCount; stats[3] = sc.maxDepthOfTree; }
+    return (int)sc.bvh.size();
+}
+
 void oracle_scene_free(void* h) { delete (OracleScene*)h; }
 
 int oracle_scene_texels(void* h) { return (int)((OracleScene*)h)->sc.textures.size(); }

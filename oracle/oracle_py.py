@@ -40,6 +40,8 @@ def lib():
         L.oracle_scene_from_arrays.restype = C.c_void_p
         L.oracle_scene_from_arrays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_build_bvh.restype = C.c_int
+        L.oracle_build_bvh.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_scene_texels.restype = C.c_int
         L.oracle_scene_texels.argtypes = [C.c_void_p]
         L.oracle_scene_free.argtypes = [C.c_void_p]
@@ -68,6 +70,19 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def build_bvh(points, mesh, max_leaf_size):
+    """buildBVH (main.cu:20-233) on raw arrays: points float4[n] bytes, mesh Triangle(80 B)[n] bytes.
+    Returns (nodes uint8[48*n_nodes], indices int32[n_tris], stats dict)."""
+    pts = np.ascontiguousarray(points).view(np.uint8).reshape(-1)
+    m = np.ascontiguousarray(mesh).view(np.uint8).reshape(-1)
+    n = m.size // 80
+    nodes = np.zeros(max(2 * n - 1, 1) * 48, np.uint8)
+    idx = np.zeros(n, np.int32)
+    st = np.zeros(4, np.int32)
+    k = lib().oracle_build_bvh(_p(pts), pts.size // 16, _p(m), n, int(max_leaf_size), _p(nodes), _p(idx), _p(st))
+    return nodes[:k * 48].copy(), idx, dict(n_nodes=int(st[0]), largest_leaf=int(st[1]), backups=int(st[2]), depth=int(st[3]))
 
 
 class OracleScene:

@@ -1,0 +1,114 @@
+"""BVH builder parity. The oracle's buildBVH (oracle/oracle_scene.cpp, following
+main.cu:20-233) is the checker; the kept host builder (novum_bvh_build_host) and the device builder
+(pt_bvh_build_device, reference-tree mode) must give its node array and BVHindices byte for byte."""
+import numpy as np
+import pytest
+
+from bvh_cases import LEAF_SIZES, cases
+from conftest import golden_scene
+
+CASES = cases()
+
+
+def _check_tree(nodes, idx, n):
+    """Structure the traversal relies on: pre-order numbering, every primitive in exactly one leaf."""
+    nd = nodes.view(np.int32).reshape(-1, 12)
+    assert sorted(idx.tolist()) == list(range(n))
+    covered, stack, expect = 0, [0], 0
+    while stack:
+        i = stack.pop()
+        assert i == expect; expect += 1               # nodes.size() at push time, main.cu:137
+        left, right, first, count = nd[i, 8:12]
+        if count > 0:
+            assert first == covered and left == -1 and right == -1
+            covered += count
+        else:
+            assert left == i + 1 and first == -1
+            stack.append(right); stack.append(left)
+    assert covered == n and expect == len(nd)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_host_builder_matches_oracle(api, oracle, name):
+    pts, mesh = CASES[name]
+    for leaf in LEAF_SIZES:
+        on, oi, ost = oracle.build_bvh(pts, mesh, leaf)
+        hn, hi, hst = api.build_bvh(pts, mesh, leaf, where="host")
+        _check_tree(on, oi, len(mesh))
+        assert np.array_equal(hi, oi), (name, leaf)
+        assert np.array_equal(hn, on), (name, leaf)
+        assert (hst["n_nodes"], hst["largest_leaf"], hst["backups"], hst["depth"]) == \
+               (ost["n_nodes"], ost["largest_leaf"], ost["backups"], ost["depth"])
+
+
+def test_cases_reach_every_branch(oracle):
+    """The adversarial sets do what they were built for (else the parity above proves less than it says)."""
+    _, _, st = oracle.build_bvh(*CASES["dupes"], 4)
+    assert st["backups"] > 0 and st["largest_leaf"] > 4           # mean retry + forced oversize leaf
+    _, _, st = oracle.build_bvh(*CASES["big_small"], 2)
+    assert st["backups"] > 0
+    _, _, st = oracle.build_bvh(*CASES["soup5k"], 4)
+    assert st["depth"] > 10
+
+
+def test_device_builder_refuses_without_gpu_or_bad_input(api):
+    pts, mesh = CASES["tiny3"]
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(api.PtError, match="no usable HIP device|hipMalloc|failed"):
+            api.build_bvh(pts, mesh, 4, where="device")
+    bad = mesh.copy(); bad[1, 0] = 10**6
+    with pytest.raises(api.PtError):
+        api.build_bvh(pts, bad, 4, where="host")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_builder_matches_oracle(api, oracle, gpu_ready, name):
+    pts, mesh = CASES[name]
+    for leaf in LEAF_SIZES:
+        on, oi, ost = oracle.build_bvh(pts, mesh, leaf)
+        dn, di, dst = api.build_bvh(pts, mesh, leaf, where="device")
+        assert np.array_equal(di, oi), (name, leaf)
+        assert np.array_equal(dn, on), (name, leaf)
+        assert (dst["n_nodes"], dst["largest_leaf"], dst["backups"], dst["depth"]) == \
+               (ost["n_nodes"], ost["largest_leaf"], ost["backups"], ost["depth"])
+        if name.startswith("slivers"):
+            assert dst["sort_fallbacks"] > 0                      # the median fallback ran on the device
+
+
+@pytest.mark.gpu
+def test_device_builder_rejects_bad_input(api, gpu_ready):
+    pts, mesh = CASES["tiny3"]
+    bad = mesh.copy(); bad[1, 0] = 10**6
+    with pytest.raises(api.PtError, match="out of range"):
+        api.build_bvh(pts, bad, 4)
+    nanp = pts.copy(); nanp[2, 1] = np.nan
+    with pytest.raises(api.PtError, match="non-finite"):
+        api.build_bvh(nanp, mesh, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cornell32", "mixed32"])
+def test_loader_with_device_builder(api, gpu_ready, scene):
+    """novum_scene_load_ex(NOVUM_BVH_DEVICE) hands pt_scene_create the same arrays as the host loader."""
+    a = api.HostScene(golden_scene(scene))
+    b = api.HostScene(golden_scene(scene), bvh_builder="device")
+    assert a.info == b.info
+    for what in ("bvh", "indices", "mesh", "points"):
+        assert np.array_equal(a.array(what), b.array(what)), what
+
+
+@pytest.mark.gpu
+def test_device_builder_large_scenes(api, oracle, gpu_ready, scene_dir):
+    """The bench scenes (82 k and 263 k triangles): device tree == host tree, and the render through it
+    is the render through the host-built one (same arrays, so this is a plumbing check)."""
+    from cudapathtracer_amd import scenes
+    for maker, kw in ((scenes.blob_in_box, {}), (scenes.atrium, {})):
+        cfg = maker(scene_dir, **kw)["config"]
+        hs = api.HostScene(cfg)
+        pts, mesh = hs.array("points"), hs.array("mesh")
+        dn, di, dst = api.build_bvh(pts, mesh, hs.info["leaf_size"])
+        assert np.array_equal(dn, hs.array("bvh")) and np.array_equal(di, hs.array("indices").view(np.int32))
+        assert dst["largest_leaf"] == hs.info["largest_leaf"] and dst["backups"] == hs.info["backup_count"]
+        hs.close()
