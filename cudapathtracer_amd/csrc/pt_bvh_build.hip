@@ -9,9 +9,11 @@
 //
 //   classify   per node      bounds -> node record; leaf test (main.cu:153); split axis (:161-168)
 //   bin        per position  12 buckets over the node bounds on the axis (:76-85); unions and counts
-//                            through order-independent atomics on order-preserving integer keys
+//                            through order-independent atomics on order-preserving integer keys,
+//                            staged in LDS per workgroup while a node is large
 //   sah        per node      the reference's cost loop incl. its right-count quirk (:90-117)
-//   (sort)     rare          median fallback (:119-128) = total-order sort of the node's range
+//   (sort)     rare          median fallback (:119-128) = total-order sort of the node's range:
+//                            rank by counting for small nodes, bitonic network for large ones
 //   flag+scan  per position  centroid < splitPos (:185-188) and an exclusive prefix sum over ALL
 //                            positions; numLeft of a node = S[end] - S[start]
 //   (mean)     rare          centroid-mean retry (:192-202): a float sum in the reference's order,
@@ -25,15 +27,17 @@
 //                            union order does not matter).
 //
 // Nodes are numbered breadth-first while building; two sweeps over the levels (subtree sizes up,
-// pre-order index down) give the reference's depth-first numbering. All float arithmetic is
-// written as the reference writes it and compiled with -ffp-contract=off.
-// min/max over boxes use the total order of the integer keys, which is fminf/fmaxf on the finite
-// values the builder accepts and puts -0 below +0 (the host builder does the same).
+// pre-order index down) give the reference's depth-first numbering. One host synchronisation per
+// level (after `sah`: it tells the host the level's node count and whether a sort is needed).
+// All float arithmetic is written as the reference writes it and compiled with -ffp-contract=off
+// (DESIGN.md §4). min/max over boxes use the total order of the integer keys, which is fminf/fmaxf
+// on the finite values the builder accepts and puts -0 below +0 (the host builder does the same).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
@@ -48,6 +52,10 @@ constexpr int NB = 12;
 constexpr int kBlock = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;
+constexpr int kStageMin = 4096;       // nodes at least this large accumulate in LDS first (atomic contention)
+constexpr int kChunks = 1024;         // workgroups of the per-position accumulation passes
+constexpr int kSortSmall = 1024;      // median fallback: rank-by-counting up to here, bitonic network above
+constexpr int kSortTile = 2048;       // keys one workgroup sorts in LDS
 
 enum : int { ST_LEAF = 1, ST_SPLITTING = 2, ST_SORT = 3, ST_OK = 4, ST_REDO = 5 };
 
@@ -60,7 +68,8 @@ struct WorkNode {                 // 64 B, one per node of the level being built
 };
 struct Bins { unsigned lo[NB][3], hi[NB][3]; int cnt[NB]; };
 struct OutNode { float lo[3], hi[3]; int left, right, first, count, size, pre; };
-struct Ctl { int nextCount, outCount, binCount, anySort, anyRedo, redoCount, largestLeaf, backups, sortFallbacks, bad; };
+struct SortRec { int w, start, end, axis; };
+struct Ctl { int curCount, nextCount, outCount, binCount, anyRedo, redoCount, sortCount, sortMax, largestLeaf, backups, sortFallbacks, bad; };
 
 __host__ __device__ inline unsigned fkey(float f) {
     unsigned u;
@@ -99,69 +108,166 @@ struct Arrays {
     Bins* bins;
     OutNode* out;
     pt_bvh_node* fin;
+    SortRec* sortRec;
+    unsigned long long* keys;
     Ctl* ctl;
 };
 
-// Union of a box into a node's key bounds. When every active lane of the wave targets the same
-// node (the top levels) the wave reduces first and issues six atomics instead of 6 x 64.
-__device__ inline void union_into(bool act, int target, unsigned* lo0, unsigned* hi0, size_t strideBytes,
-                                  const unsigned kl[3], const unsigned kh[3]) {
+// ---- accumulation of boxes into per-node slots ---------------------------------------------------
+// A "slot" is one box (+ count) of a node: its 12 buckets (bin), its two children (scatter), or the
+// root itself (prims). Small nodes take global atomics directly. A node of kStageMin primitives or
+// more would put thousands of atomics on the same few words, so a workgroup walking its contiguous
+// chunk of positions accumulates the node it is currently in in LDS and flushes once per node.
+template <int S> struct StageMem { unsigned lo[S * 3], hi[S * 3]; int cnt[S]; int cand; };
+
+template <int S> __device__ inline void stage_reset(StageMem<S>& m) {
+    for (int t = threadIdx.x; t < S * 3; t += blockDim.x) { m.lo[t] = 0xffffffffu; m.hi[t] = 0u; }
+    for (int t = threadIdx.x; t < S; t += blockDim.x) m.cnt[t] = 0;
+}
+template <int S, class Dest> __device__ inline void stage_flush(StageMem<S>& m, int cur, const Dest& dest) {
+    __syncthreads();
+    if (cur >= 0) {
+        for (int t = threadIdx.x; t < S * 3; t += blockDim.x) {
+            int slot = t / 3, k = t - 3 * slot;
+            unsigned l = m.lo[t], h = m.hi[t];
+            if (l != 0xffffffffu) atomicMin(dest.lo(cur, slot) + k, l);
+            if (h != 0u) atomicMax(dest.hi(cur, slot) + k, h);
+            m.lo[t] = 0xffffffffu; m.hi[t] = 0u;
+        }
+        for (int t = threadIdx.x; t < S; t += blockDim.x) {
+            int c = m.cnt[t];
+            if (c) { int* p = dest.cnt(cur, t); if (p) atomicAdd(p, c); }
+            m.cnt[t] = 0;
+        }
+    }
+    __syncthreads();
+}
+// One tile of the workgroup's chunk: lanes with `pend` add (kl, kh) to slot `slot` of node `node`.
+// Must be called by every thread of the workgroup. `cur` is the node currently held in LDS.
+template <int S, class Dest>
+__device__ inline void stage_add(StageMem<S>& m, int& cur, bool pend, int node, int slot, const unsigned kl[3], const unsigned kh[3], const Dest& dest) {
+    for (;;) {
+        if (threadIdx.x == 0) m.cand = INT_MAX;
+        __syncthreads();
+        if (pend) atomicMin(&m.cand, node);
+        __syncthreads();
+        const int cand = m.cand;
+        if (cand == INT_MAX) break;
+        if (cand != cur) { stage_flush(m, cur, dest); cur = cand; }
+        const bool sel = pend && node == cand;
+        unsigned long long rem = __ballot(sel);
+        while (rem) {
+            int l = __ffsll((unsigned long long)rem) - 1;
+            int s0 = __shfl(slot, l);
+            bool ss = sel && slot == s0;
+            unsigned long long sm = __ballot(ss);
+            unsigned r[6];
+            for (int k = 0; k < 3; k++) { r[k] = wave_min(ss ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(ss ? kh[k] : 0u); }
+            if (lane_id() == l) {
+                for (int k = 0; k < 3; k++) { atomicMin(&m.lo[s0 * 3 + k], r[k]); atomicMax(&m.hi[s0 * 3 + k], r[3 + k]); }
+                atomicAdd(&m.cnt[s0], (int)__popcll(sm));
+            }
+            rem &= ~sm;
+        }
+        pend = pend && !sel;
+        __syncthreads();
+    }
+}
+// Direct path for small nodes: when the whole wave works on one node, reduce per slot first.
+template <class Dest>
+__device__ inline void direct_add(bool act, int node, int slot, const unsigned kl[3], const unsigned kh[3], const Dest& dest) {
     unsigned long long am = __ballot(act);
     if (am == 0) return;
-    unsigned long long rem = am;
-    // at most two distinct targets are reduced wave-wide; anything beyond falls back to per-lane atomics
-    for (int round = 0; round < 2 && rem; round++) {
-        int l = __ffsll((unsigned long long)rem) - 1;
-        int t0 = __shfl(target, l);
-        bool sel = act && target == t0;
-        unsigned long long sm = __ballot(sel);
-        if (__popcll(sm) >= 8) {
+    int lead = __ffsll((unsigned long long)am) - 1;
+    bool uniform = __all(!act || node == __shfl(node, lead)) != 0;
+    if (uniform) {
+        int n0 = __shfl(node, lead);
+        unsigned long long rem = am;
+        while (rem) {
+            int l = __ffsll((unsigned long long)rem) - 1;
+            int s0 = __shfl(slot, l);
+            bool ss = act && slot == s0;
+            unsigned long long sm = __ballot(ss);
             unsigned r[6];
-            for (int k = 0; k < 3; k++) { r[k] = wave_min(sel ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(sel ? kh[k] : 0u); }
+            for (int k = 0; k < 3; k++) { r[k] = wave_min(ss ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(ss ? kh[k] : 0u); }
             if (lane_id() == l) {
-                unsigned* L = (unsigned*)((char*)lo0 + (size_t)t0 * strideBytes);
-                unsigned* H = (unsigned*)((char*)hi0 + (size_t)t0 * strideBytes);
-                for (int k = 0; k < 3; k++) { atomicMin(L + k, r[k]); atomicMax(H + k, r[3 + k]); }
+                for (int k = 0; k < 3; k++) { atomicMin(dest.lo(n0, s0) + k, r[k]); atomicMax(dest.hi(n0, s0) + k, r[3 + k]); }
+                int* c = dest.cnt(n0, s0);
+                if (c) atomicAdd(c, (int)__popcll(sm));
             }
-            act = act && !sel;
+            rem &= ~sm;
         }
-        rem &= ~sm;
-    }
-    if (act) {
-        unsigned* L = (unsigned*)((char*)lo0 + (size_t)target * strideBytes);
-        unsigned* H = (unsigned*)((char*)hi0 + (size_t)target * strideBytes);
-        for (int k = 0; k < 3; k++) { atomicMin(L + k, kl[k]); atomicMax(H + k, kh[k]); }
+    } else if (act) {
+        for (int k = 0; k < 3; k++) { atomicMin(dest.lo(node, slot) + k, kl[k]); atomicMax(dest.hi(node, slot) + k, kh[k]); }
+        int* c = dest.cnt(node, slot);
+        if (c) atomicAdd(c, 1);
     }
 }
 
+struct RootDest {
+    WorkNode* root;
+    __device__ unsigned* lo(int, int) const { return root->lo; }
+    __device__ unsigned* hi(int, int) const { return root->hi; }
+    __device__ int* cnt(int, int) const { return nullptr; }
+};
+struct BinDest {
+    const WorkNode* work; Bins* bins;
+    __device__ unsigned* lo(int w, int b) const { return bins[work[w].bin].lo[b]; }
+    __device__ unsigned* hi(int w, int b) const { return bins[work[w].bin].hi[b]; }
+    __device__ int* cnt(int w, int b) const { return &bins[work[w].bin].cnt[b]; }
+};
+struct ChildDest {
+    const WorkNode* work; WorkNode* next;
+    __device__ unsigned* lo(int w, int c) const { return next[work[w].child + c].lo; }
+    __device__ unsigned* hi(int w, int c) const { return next[work[w].child + c].hi; }
+    __device__ int* cnt(int, int) const { return nullptr; }
+};
+
 // computeInfoForBVH, main.cu:20-47, plus the root's bounds and the identity permutation (:503-504).
-__global__ void k_prims(Arrays A) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = i < A.n;
-    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
-    if (ok) {
-        pt_triangle t = A.mesh[i];
-        int ia = t.aInd, ib = t.bInd, ic = t.cInd;
-        if ((unsigned)ia >= (unsigned)A.nPos || (unsigned)ib >= (unsigned)A.nPos || (unsigned)ic >= (unsigned)A.nPos) { A.ctl->bad = 1; ia = ib = ic = 0; }
-        pt_float4 a = A.pos[ia], b = A.pos[ib], c = A.pos[ic];
-        float mx = fminf(fminf(a.x, b.x), c.x) - 0.000001f, my = fminf(fminf(a.y, b.y), c.y) - 0.000001f, mz = fminf(fminf(a.z, b.z), c.z) - 0.000001f;
-        float Mx = fmaxf(fmaxf(a.x, b.x), c.x) + 0.000001f, My = fmaxf(fmaxf(a.y, b.y), c.y) + 0.000001f, Mz = fmaxf(fmaxf(a.z, b.z), c.z) + 0.000001f;
-        A.cx[i] = (a.x + b.x + c.x) / 3.0f; A.cy[i] = (a.y + b.y + c.y) / 3.0f; A.cz[i] = (a.z + b.z + c.z) / 3.0f;
-        A.lo[i] = make_float4(mx, my, mz, 0.0f); A.hi[i] = make_float4(Mx, My, Mz, 0.0f);
-        // non-finite geometry has no defined tree in the reference either (NaN compares); refuse it
-        float big = fmaxf(fmaxf(fabsf(mx), fabsf(my)), fmaxf(fmaxf(fabsf(mz), fabsf(Mx)), fmaxf(fabsf(My), fabsf(Mz))));
-        float any = ((a.x + a.y + a.z) + (b.x + b.y + b.z)) + (c.x + c.y + c.z);          // NaN anywhere -> NaN
-        if (!(big <= 1e37f) || any != any) A.ctl->bad = 2;
-        A.idxA[i] = i; A.nodeA[i] = 0; A.nodeB[i] = -1;
-        kl[0] = fkey(mx); kl[1] = fkey(my); kl[2] = fkey(mz); kh[0] = fkey(Mx); kh[1] = fkey(My); kh[2] = fkey(Mz);
+__global__ __launch_bounds__(kBlock) void k_prims(Arrays A, int chunk) {
+    __shared__ StageMem<1> sm;
+    stage_reset(sm);
+    __syncthreads();
+    int cur = -1;
+    const RootDest dest{A.workA};
+    const bool staged = A.n >= kStageMin;
+    const int b0 = blockIdx.x * chunk, b1 = min(A.n, b0 + chunk);
+    for (int base = b0; base < b1; base += kBlock) {
+        int i = base + threadIdx.x;
+        bool ok = i < b1;
+        unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+        if (ok) {
+            pt_triangle t = A.mesh[i];
+            int ia = t.aInd, ib = t.bInd, ic = t.cInd;
+            if ((unsigned)ia >= (unsigned)A.nPos || (unsigned)ib >= (unsigned)A.nPos || (unsigned)ic >= (unsigned)A.nPos) { A.ctl->bad = 1; ia = ib = ic = 0; }
+            pt_float4 a = A.pos[ia], b = A.pos[ib], c = A.pos[ic];
+            float mx = fminf(fminf(a.x, b.x), c.x) - 0.000001f, my = fminf(fminf(a.y, b.y), c.y) - 0.000001f, mz = fminf(fminf(a.z, b.z), c.z) - 0.000001f;
+            float Mx = fmaxf(fmaxf(a.x, b.x), c.x) + 0.000001f, My = fmaxf(fmaxf(a.y, b.y), c.y) + 0.000001f, Mz = fmaxf(fmaxf(a.z, b.z), c.z) + 0.000001f;
+            A.cx[i] = (a.x + b.x + c.x) / 3.0f; A.cy[i] = (a.y + b.y + c.y) / 3.0f; A.cz[i] = (a.z + b.z + c.z) / 3.0f;
+            A.lo[i] = make_float4(mx, my, mz, 0.0f); A.hi[i] = make_float4(Mx, My, Mz, 0.0f);
+            // non-finite geometry has no defined tree in the reference either (NaN compares); refuse it
+            float big = fmaxf(fmaxf(fabsf(mx), fabsf(my)), fmaxf(fmaxf(fabsf(mz), fabsf(Mx)), fmaxf(fabsf(My), fabsf(Mz))));
+            float any = ((a.x + a.y + a.z) + (b.x + b.y + b.z)) + (c.x + c.y + c.z);          // NaN anywhere -> NaN
+            if (!(big <= 1e37f) || any != any) A.ctl->bad = 2;
+            A.idxA[i] = i; A.nodeA[i] = 0; A.nodeB[i] = -1;
+            kl[0] = fkey(mx); kl[1] = fkey(my); kl[2] = fkey(mz); kh[0] = fkey(Mx); kh[1] = fkey(My); kh[2] = fkey(Mz);
+        }
+        if (staged) stage_add(sm, cur, ok, 0, 0, kl, kh, dest);
+        else direct_add(ok, 0, 0, kl, kh, dest);
     }
-    union_into(ok, 0, A.workA[0].lo, A.workA[0].hi, sizeof(WorkNode), kl, kh);
+    stage_flush(sm, cur, dest);
+}
+
+__global__ void k_next_level(Arrays A) {
+    Ctl& c = *A.ctl;
+    c.curCount = c.nextCount;
+    c.nextCount = 0; c.binCount = 0; c.anyRedo = 0; c.redoCount = 0; c.sortCount = 0; c.sortMax = 0;
 }
 
 // Node record + leaf test + axis choice, main.cu:139-168.
-__global__ void k_classify(Arrays A, WorkNode* work, int W, int leafMax) {
+__global__ void k_classify(Arrays A, WorkNode* work, int leafMax) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+    if (w >= A.ctl->curCount) return;
     WorkNode nd = work[w];
     OutNode& o = A.out[nd.out];
     float mn[3], mx[3];
@@ -183,49 +289,35 @@ __global__ void k_classify(Arrays A, WorkNode* work, int W, int leafMax) {
 }
 
 // Bucket fill, main.cu:76-85.
-__global__ void k_bin(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int w = p < A.n ? nodeOf[p] : -1;
-    bool act = w >= 0 && work[w].state == ST_SPLITTING;
-    int b = 0, bin = 0;
-    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
-    if (act) {
-        const WorkNode& nd = work[w];
-        int id = idx[p], axis = nd.axis;
-        bin = nd.bin;
-        float a0 = funkey(nd.lo[axis]), ext = funkey(nd.hi[axis]) - a0;
-        float q = NB * (comp3(A.cx, A.cy, A.cz, axis, id) - a0) / ext;
-        b = (q == q && fabsf(q) < 1e9f) ? (int)q : 0;               // int(NaN/inf) is UB in the reference; defined 0
-        b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
-        float4 l = A.lo[id], h = A.hi[id];
-        kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
-    }
-    unsigned long long am = __ballot(act);
-    if (am == 0) return;
-    int lead = __ffsll((unsigned long long)am) - 1;
-    bool uniform = __all(!act || bin == __shfl(bin, lead)) != 0;
-    if (uniform) {
-        int bin0 = __shfl(bin, lead);
-        Bins& B = A.bins[bin0];
-        unsigned long long rem = am;
-        while (rem) {
-            int l = __ffsll((unsigned long long)rem) - 1;
-            int b0 = __shfl(b, l);
-            bool sel = act && b == b0;
-            unsigned long long sm = __ballot(sel);
-            unsigned r[6];
-            for (int k = 0; k < 3; k++) { r[k] = wave_min(sel ? kl[k] : 0xffffffffu); r[3 + k] = wave_max(sel ? kh[k] : 0u); }
-            if (lane_id() == l) {
-                for (int k = 0; k < 3; k++) { atomicMin(&B.lo[b0][k], r[k]); atomicMax(&B.hi[b0][k], r[3 + k]); }
-                atomicAdd(&B.cnt[b0], (int)__popcll(sm));
-            }
-            rem &= ~sm;
+__global__ __launch_bounds__(kBlock) void k_bin(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf, int chunk) {
+    __shared__ StageMem<NB> sm;
+    stage_reset(sm);
+    __syncthreads();
+    int cur = -1;
+    const BinDest dest{work, A.bins};
+    const int b0 = blockIdx.x * chunk, b1 = min(A.n, b0 + chunk);
+    for (int base = b0; base < b1; base += kBlock) {
+        int p = base + threadIdx.x;
+        int w = p < b1 ? nodeOf[p] : -1;
+        bool act = w >= 0 && work[w].state == ST_SPLITTING;
+        int b = 0;
+        bool big = false;
+        unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+        if (act) {
+            const WorkNode& nd = work[w];
+            int id = idx[p], axis = nd.axis;
+            big = nd.end - nd.start >= kStageMin;
+            float a0 = funkey(nd.lo[axis]), ext = funkey(nd.hi[axis]) - a0;
+            float q = NB * (comp3(A.cx, A.cy, A.cz, axis, id) - a0) / ext;
+            b = (q == q && fabsf(q) < 1e9f) ? (int)q : 0;           // int(NaN/inf) is UB in the reference; defined 0
+            b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+            float4 l = A.lo[id], h = A.hi[id];
+            kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
         }
-    } else if (act) {
-        Bins& B = A.bins[bin];
-        for (int k = 0; k < 3; k++) { atomicMin(&B.lo[b][k], kl[k]); atomicMax(&B.hi[b][k], kh[k]); }
-        atomicAdd(&B.cnt[b], 1);
+        direct_add(act && !big, w, b, kl, kh, dest);
+        stage_add(sm, cur, act && big, w, b, kl, kh, dest);
     }
+    stage_flush(sm, cur, dest);
 }
 
 __device__ inline float area_keys(const unsigned lo[3], const unsigned hi[3]) {   // surfaceArea, util.cuh:225-231
@@ -234,9 +326,9 @@ __device__ inline float area_keys(const unsigned lo[3], const unsigned hi[3]) { 
 }
 
 // Cost sweep, main.cu:87-131. Right side: bucket i is counted twice (:102-109), kept.
-__global__ void k_sah(Arrays A, WorkNode* work, int W) {
+__global__ void k_sah(Arrays A, WorkNode* work) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+    if (w >= A.ctl->curCount) return;
     if (work[w].state != ST_SPLITTING) return;
     WorkNode nd = work[w];
     const Bins& B = A.bins[nd.bin];
@@ -261,7 +353,8 @@ __global__ void k_sah(Arrays A, WorkNode* work, int W) {
     }
     if (bestI < 0) {
         work[w].state = ST_SORT;
-        A.ctl->anySort = 1;
+        A.sortRec[atomicAdd(&A.ctl->sortCount, 1)] = SortRec{w, nd.start, nd.end, nd.axis};
+        atomicMax(&A.ctl->sortMax, nd.end - nd.start);
         atomicAdd(&A.ctl->sortFallbacks, 1);
     } else {
         float a0 = funkey(nd.lo[nd.axis]), ext = funkey(nd.hi[nd.axis]) - a0;
@@ -270,14 +363,14 @@ __global__ void k_sah(Arrays A, WorkNode* work, int W) {
 }
 
 // Median fallback, main.cu:119-128: nth_element's permutation is STL-specific; SURVEY App. D fixes
-// it as a sort by (centroid[axis], index). Rank by counting — rare and small in practice.
+// it as a sort by (centroid[axis], index). Nodes up to kSortSmall: rank by counting.
 __global__ void k_sort_rank(Arrays A, const WorkNode* work, const int* idx, const int* nodeOf) {
-    if (!A.ctl->anySort) return;
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.n) return;
     int w = nodeOf[p];
     if (w < 0 || work[w].state != ST_SORT) return;
     const WorkNode& nd = work[w];
+    if (nd.end - nd.start > kSortSmall) return;
     int me = idx[p], axis = nd.axis, rank = 0;
     float ca = comp3(A.cx, A.cy, A.cz, axis, me);
     for (int j = nd.start; j < nd.end; j++) {
@@ -288,14 +381,60 @@ __global__ void k_sort_rank(Arrays A, const WorkNode* work, const int* idx, cons
     A.tmp[nd.start + rank] = me;
 }
 __global__ void k_sort_apply(Arrays A, WorkNode* work, int* idx, const int* nodeOf) {
-    if (!A.ctl->anySort) return;
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.n) return;
     int w = nodeOf[p];
     if (w < 0 || work[w].state != ST_SORT) return;
+    if (work[w].end - work[w].start > kSortSmall) return;
     int id = A.tmp[p];
     idx[p] = id;
     if (p == (work[w].start + work[w].end) / 2) work[w].split = comp3(A.cx, A.cy, A.cz, work[w].axis, id);
+}
+// Larger nodes: bitonic network on 64-bit keys (centroid key << 32 | index — the same total order,
+// since centroid keys are ordered like the floats and the builder refuses NaN), padded with ~0 to a
+// power of two P >= kSortTile. Strides below kSortTile run in LDS.
+__global__ void k_sort_load(Arrays A, const int* idx, SortRec r, int P) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    unsigned long long k = ~0ull;
+    if (i < r.end - r.start) {
+        int id = idx[r.start + i];
+        k = ((unsigned long long)fkey(comp3(A.cx, A.cy, A.cz, r.axis, id)) << 32) | (unsigned)id;
+    }
+    A.keys[i] = k;
+}
+__global__ void k_bitonic_global(unsigned long long* keys, int k, int j) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;          // one thread per pair
+    int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+    unsigned long long a = keys[lo], b = keys[hi];
+    bool up = (lo & k) == 0;
+    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+}
+__global__ __launch_bounds__(kBlock) void k_bitonic_lds(unsigned long long* keys, int kFrom, int kTo) {
+    __shared__ unsigned long long s[kSortTile];
+    const int base = blockIdx.x * kSortTile;
+    for (int t = threadIdx.x; t < kSortTile; t += kBlock) s[t] = keys[base + t];
+    __syncthreads();
+    for (int k = kFrom; k <= kTo; k <<= 1) {
+        for (int j = min(k >> 1, kSortTile >> 1); j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kSortTile / 2; i += kBlock) {
+                int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                unsigned long long a = s[lo], b = s[hi];
+                bool up = ((base + lo) & k) == 0;
+                if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+        if (k > INT_MAX / 2) break;
+    }
+    for (int t = threadIdx.x; t < kSortTile; t += kBlock) keys[base + t] = s[t];
+}
+__global__ void k_sort_store(Arrays A, WorkNode* work, int* idx, SortRec r) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r.end - r.start) return;
+    int id = (int)(unsigned)(A.keys[i] & 0xffffffffull);
+    idx[r.start + i] = id;
+    if (r.start + i == (r.start + r.end) / 2) work[r.w].split = comp3(A.cx, A.cy, A.cz, r.axis, id);
 }
 
 // centroid[axis] < splitPos, main.cu:185-188 (first pass) and :206-209 (after the mean retry).
@@ -373,10 +512,10 @@ __global__ void k_scan3(Arrays A, int gated) {
 }
 
 // numLeft test, main.cu:189-190 (pass 0) and :210-221 (pass 1: forced, possibly oversize, leaf).
-__global__ void k_check(Arrays A, WorkNode* work, int W, int pass) {
+__global__ void k_check(Arrays A, WorkNode* work, int pass) {
     if (pass == 1 && !A.ctl->anyRedo) return;
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+    if (w >= A.ctl->curCount) return;
     int st = work[w].state;
     if (pass == 0 ? (st != ST_SPLITTING && st != ST_SORT) : st != ST_REDO) return;
     int s = work[w].start, e = work[w].end, n = e - s;
@@ -415,9 +554,9 @@ __global__ void k_mean(Arrays A, WorkNode* work, const int* idx) {
 }
 
 // Children of the nodes that split, main.cu:226-227 (numbered later).
-__global__ void k_alloc(Arrays A, WorkNode* work, WorkNode* next, int W) {
+__global__ void k_alloc(Arrays A, WorkNode* work, WorkNode* next) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+    if (w >= A.ctl->curCount) return;
     if (work[w].state != ST_OK) return;
     int c = atomicAdd(&A.ctl->nextCount, 2), o = atomicAdd(&A.ctl->outCount, 2);
     int s = work[w].start, e = work[w].end, mid = s + work[w].numLeft;
@@ -443,37 +582,44 @@ __global__ void k_goodpos(Arrays A, const WorkNode* work, const int* nodeOf) {
 }
 
 // partitionPrimitives, main.cu:49-62, in closed form (header); child bounds, main.cu:139-148.
-__global__ void k_scatter(Arrays A, const WorkNode* work, WorkNode* next, const int* idx, int* idxOut, int* nodeOf, int* nodeOut) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    int w = p < A.n ? nodeOf[p] : -1;
-    int st = w >= 0 ? work[w].state : 0;
-    bool act = st == ST_OK;
-    int child = 0;
-    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
-    if (st == ST_LEAF) { idxOut[p] = idx[p]; nodeOut[p] = -1; nodeOf[p] = -1; }
-    if (act) {
-        const WorkNode& nd = work[w];
-        int s = nd.start, nl = nd.numLeft, id = idx[p], dest;
-        if (A.F[p]) dest = s + (A.S[p] - A.S[s]);
-        else {
-            dest = p;
-            while (dest - s < nl) {
-                int to = A.g[dest];
-                if (to <= dest) { A.ctl->bad = 3; break; }          // cannot happen (header); never spin on the GPU
-                dest = to;
+__global__ __launch_bounds__(kBlock) void k_scatter(Arrays A, const WorkNode* work, WorkNode* next, const int* idx, int* idxOut,
+                                                    int* nodeOf, int* nodeOut, int chunk) {
+    __shared__ StageMem<2> sm;
+    stage_reset(sm);
+    __syncthreads();
+    int cur = -1;
+    const ChildDest dest{work, next};
+    const int b0 = blockIdx.x * chunk, b1 = min(A.n, b0 + chunk);
+    for (int base = b0; base < b1; base += kBlock) {
+        int p = base + threadIdx.x;
+        int w = p < b1 ? nodeOf[p] : -1;
+        int st = w >= 0 ? work[w].state : 0;
+        bool act = st == ST_OK, big = false;
+        int side = 0;
+        unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+        if (st == ST_LEAF) { idxOut[p] = idx[p]; nodeOut[p] = -1; nodeOf[p] = -1; }
+        if (act) {
+            const WorkNode& nd = work[w];
+            int s = nd.start, nl = nd.numLeft, id = idx[p], dst;
+            big = nd.end - s >= kStageMin;
+            if (A.F[p]) dst = s + (A.S[p] - A.S[s]);
+            else {
+                dst = p;
+                while (dst - s < nl) {
+                    int to = A.g[dst];
+                    if (to <= dst) { A.ctl->bad = 3; break; }       // cannot happen (header); never spin on the GPU
+                    dst = to;
+                }
             }
+            side = dst < s + nl ? 0 : 1;
+            idxOut[dst] = id; nodeOut[dst] = nd.child + side;
+            float4 l = A.lo[id], h = A.hi[id];
+            kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
         }
-        child = nd.child + (dest < s + nl ? 0 : 1);
-        idxOut[dest] = id; nodeOut[dest] = child;
-        float4 l = A.lo[id], h = A.hi[id];
-        kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
+        direct_add(act && !big, w, side, kl, kh, dest);
+        stage_add(sm, cur, act && big, w, side, kl, kh, dest);
     }
-    union_into(act, child, next[0].lo, next[0].hi, sizeof(WorkNode), kl, kh);
-}
-
-__global__ void k_next_level(Arrays A) {
-    Ctl& c = *A.ctl;
-    c.nextCount = 0; c.binCount = 0; c.anySort = 0; c.anyRedo = 0; c.redoCount = 0;
+    stage_flush(sm, cur, dest);
 }
 
 // ---- breadth-first -> the reference's depth-first numbering (nodes.size() at push, main.cu:137) ----
@@ -523,6 +669,8 @@ void carve(Carver& c, Arrays& A, int n, int nPos, int maxBins) {
     A.tmp = c.take<int>(n); A.S = c.take<int>((size_t)n + 1); A.g = c.take<int>(n);
     A.blockSum = c.take<int>((size_t)blocks(n, kScanTile) + 1);
     A.redoList = c.take<int>(maxBins);
+    A.sortRec = c.take<SortRec>(maxBins);
+    A.keys = c.take<unsigned long long>(2 * (size_t)n + kSortTile);
     A.F = c.take<unsigned char>((size_t)n + 16);
     A.workA = c.take<WorkNode>((size_t)n + 2); A.workB = c.take<WorkNode>((size_t)n + 2);
     A.bins = c.take<Bins>(maxBins);
@@ -550,7 +698,7 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     if (mode != PT_BVH_REFERENCE_TREE) return pt_fail_(-3, "pt_bvh_build_device: only PT_BVH_REFERENCE_TREE (0) is built");
     if (!positions || !triangles || !nodes_out || !indices_out) return pt_fail_(-1, "pt_bvh_build_device: null argument");
     if (n_triangles <= 0 || n_positions <= 0) return pt_fail_(-1, "pt_bvh_build_device: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
-    if (n_triangles > (1 << 30)) return pt_fail_(-1, "pt_bvh_build_device: more than 2^30 triangles");
+    if (n_triangles > (1 << 28)) return pt_fail_(-1, "pt_bvh_build_device: more than 2^28 triangles");
     if (max_leaf_size < 0) return pt_fail_(-1, "pt_bvh_build_device: negative leaf size");
     const int n = n_triangles;
     {
@@ -574,41 +722,33 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     BVH_HIP(hipEventCreate(&ev0)); BVH_HIP(hipEventCreate(&ev1));
     BVH_HIP(hipMemcpy((void*)A.pos, positions, sizeof(pt_float4) * (size_t)n_positions, hipMemcpyHostToDevice));
     BVH_HIP(hipMemcpy((void*)A.mesh, triangles, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice));
+
     Ctl ctl{};
-    ctl.outCount = 1;
+    ctl.nextCount = 1; ctl.outCount = 1;
     BVH_HIP(hipMemcpy(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
     WorkNode root{};
     root.start = 0; root.end = n; root.out = 0; root.child = -1; root.bin = -1;
     for (int k = 0; k < 3; k++) { root.lo[k] = 0xffffffffu; root.hi[k] = 0u; }
     BVH_HIP(hipMemcpy(A.workA, &root, sizeof(root), hipMemcpyHostToDevice));
     const int gN = blocks(n), gScan = blocks(n, kScanTile);
+    const int gChunk = std::min(kChunks, gN);
+    const int chunk = ((n + gChunk - 1) / gChunk + kBlock - 1) / kBlock * kBlock;      // positions per workgroup, multiple of the tile
     BVH_HIP(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(k_prims, dim3(gN), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(k_prims, dim3(gChunk), dim3(kBlock), 0, st, A, chunk);
 
-    std::vector<int> levelOff{0, 1};      // out ids of level l are [levelOff[l], levelOff[l+1])
+    std::vector<int> levelOff{0};         // out ids of level l are [levelOff[l], levelOff[l+1])
+    std::vector<SortRec> recs;
     WorkNode *work = A.workA, *next = A.workB;
     int *idx = A.idxA, *idxOut = A.idxB, *nodeOf = A.nodeA, *nodeOut = A.nodeB;
-    int W = 1, levels = 0;
-    while (W > 0) {
-        levels++;
+    int levels = 0;
+    long long bound = 1;                  // upper bound of the level's node count before the host knows it
+    for (;;) {
         if (levels > 4096) { (void)hipFree(pool); return pt_fail_(-4, "pt_bvh_build_device: more than 4096 levels"); }
-        const int gW = blocks(W);
-        hipLaunchKernelGGL(k_classify, dim3(gW), dim3(kBlock), 0, st, A, work, W, max_leaf_size);
-        hipLaunchKernelGGL(k_bin, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
-        hipLaunchKernelGGL(k_sah, dim3(gW), dim3(kBlock), 0, st, A, work, W);
-        hipLaunchKernelGGL(k_sort_rank, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
-        hipLaunchKernelGGL(k_sort_apply, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
-        for (int pass = 0; pass < 2; pass++) {
-            hipLaunchKernelGGL(k_flag, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf, pass);
-            hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, A, pass);
-            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, A, gScan, pass);
-            hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, A, pass);
-            hipLaunchKernelGGL(k_check, dim3(gW), dim3(kBlock), 0, st, A, work, W, pass);
-            if (pass == 0) hipLaunchKernelGGL(k_mean, dim3(std::min(gW, 2048)), dim3(kBlock), 0, st, A, work, idx);
-        }
-        hipLaunchKernelGGL(k_alloc, dim3(gW), dim3(kBlock), 0, st, A, work, next, W);
-        hipLaunchKernelGGL(k_goodpos, dim3(gN), dim3(kBlock), 0, st, A, work, nodeOf);
-        hipLaunchKernelGGL(k_scatter, dim3(gN), dim3(kBlock), 0, st, A, work, next, idx, idxOut, nodeOf, nodeOut);
+        const int gB = blocks(std::min<long long>(bound, n));
+        hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, A);
+        hipLaunchKernelGGL(k_classify, dim3(gB), dim3(kBlock), 0, st, A, work, max_leaf_size);
+        hipLaunchKernelGGL(k_bin, dim3(gChunk), dim3(kBlock), 0, st, A, work, idx, nodeOf, chunk);
+        hipLaunchKernelGGL(k_sah, dim3(gB), dim3(kBlock), 0, st, A, work);
         BVH_HIP(hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         if (ctl.bad) {
@@ -617,10 +757,46 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
                                           : ctl.bad == 2 ? "pt_bvh_build_device: non-finite vertex position (the reference's tree is undefined for it)"
                                                          : "pt_bvh_build_device: internal error, partition chain did not advance");
         }
-        W = ctl.nextCount;
+        const int W = ctl.curCount;
+        if (W == 0) break;
+        levels++;
         levelOff.push_back(ctl.outCount);
-        hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, A);
+        const int gW = blocks(W);
+        if (ctl.sortCount > 0) {
+            if (ctl.sortMax > kSortSmall) {
+                recs.resize(ctl.sortCount);
+                BVH_HIP(hipMemcpy(recs.data(), A.sortRec, sizeof(SortRec) * recs.size(), hipMemcpyDeviceToHost));
+                for (const SortRec& r : recs) {
+                    const int m = r.end - r.start;
+                    if (m <= kSortSmall) continue;
+                    int P = kSortTile;
+                    while (P < m) P <<= 1;
+                    hipLaunchKernelGGL(k_sort_load, dim3(blocks(P)), dim3(kBlock), 0, st, A, idx, r, P);
+                    hipLaunchKernelGGL(k_bitonic_lds, dim3(P / kSortTile), dim3(kBlock), 0, st, A.keys, 2, kSortTile);
+                    for (int k = 2 * kSortTile; k <= P; k <<= 1) {
+                        for (int j = k >> 1; j >= kSortTile; j >>= 1)
+                            hipLaunchKernelGGL(k_bitonic_global, dim3(P / 2 / kBlock), dim3(kBlock), 0, st, A.keys, k, j);
+                        hipLaunchKernelGGL(k_bitonic_lds, dim3(P / kSortTile), dim3(kBlock), 0, st, A.keys, k, k);
+                    }
+                    hipLaunchKernelGGL(k_sort_store, dim3(blocks(m)), dim3(kBlock), 0, st, A, work, idx, r);
+                }
+            }
+            hipLaunchKernelGGL(k_sort_rank, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
+            hipLaunchKernelGGL(k_sort_apply, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf);
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            hipLaunchKernelGGL(k_flag, dim3(gN), dim3(kBlock), 0, st, A, work, idx, nodeOf, pass);
+            hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, A, pass);
+            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, A, gScan, pass);
+            hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, A, pass);
+            hipLaunchKernelGGL(k_check, dim3(gW), dim3(kBlock), 0, st, A, work, pass);
+            if (pass == 0) hipLaunchKernelGGL(k_mean, dim3(std::min(gW, 2048)), dim3(kBlock), 0, st, A, work, idx);
+        }
+        hipLaunchKernelGGL(k_alloc, dim3(gW), dim3(kBlock), 0, st, A, work, next);
+        hipLaunchKernelGGL(k_goodpos, dim3(gN), dim3(kBlock), 0, st, A, work, nodeOf);
+        hipLaunchKernelGGL(k_scatter, dim3(gChunk), dim3(kBlock), 0, st, A, work, next, idx, idxOut, nodeOf, nodeOut, chunk);
         std::swap(work, next); std::swap(idx, idxOut); std::swap(nodeOf, nodeOut);
+        bound = 2LL * W;
     }
     // after the last level both index buffers agree on every position (leaves copy, splits scatter)
     const int total = ctl.outCount;

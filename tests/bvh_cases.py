@@ -64,6 +64,13 @@ def cases():
     out["slivers"] = arrays_of(s)
     # same, with exactly equal centroids in pairs (the index tie-break of the fallback's order)
     out["slivers_tied"] = arrays_of(np.concatenate([s[:200], s[:200]]))
+    # enough of them that the device builder's large-node sort (bitonic network) runs, ties included
+    sb = np.zeros((5000, 3, 3), np.float32)
+    sb[:, 0] = [-10, 0, 0]; sb[:, 1] = [10, 0, 0]; sb[:, 2] = [0, 0.01, 0]
+    sb[:, :, 1] += (rng.random((5000, 1)) * 0.5).astype(np.float32)
+    sb[:, :, 2] += (rng.random((5000, 1)) * 0.5).astype(np.float32)
+    sb[:, 2, 0] += np.round(rng.random(5000) * 40 - 20).astype(np.float32) / 100
+    out["slivers_big"] = arrays_of(sb)
     # one huge triangle over many small ones: the best split isolates one primitive on the right
     big = np.array([[[-50, -50, -1], [50, -50, -1], [0, 80, -1]]], np.float32)
     out["big_small"] = arrays_of(np.concatenate([_soup(rng, 2000, box=1.0), big, _soup(rng, 50, box=30.0, size=5.0)]))
