@@ -62,6 +62,7 @@ struct pt_scene {
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
+    bool xcdBands = false;       // PT_XCD_BANDS=1: one contiguous band of tiles per XCD (A/B; loses to interleaving)
     bool deferShadow = false;    // PT_DEFER_SHADOW=1: megakernel traces shadow + extension ray as a pair (A/B; slower)
     float lastKernelMs = 0.0f;
     bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
@@ -274,6 +275,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
+    if (const char* e = getenv("PT_XCD_BANDS")) s->xcdBands = (e[0] == '1');
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->numCU = prop.multiProcessorCount;
@@ -386,6 +388,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
+    P.xcdBands = s->xcdBands ? 1 : 0;
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;

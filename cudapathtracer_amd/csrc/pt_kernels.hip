@@ -105,7 +105,18 @@ megakernel(KParams P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lt = blockIdx.x * 4 + wave;
+    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2. Default: tile =
+    // blockIdx order, i.e. the XCDs interleave over the frame at 32x8-pixel granularity — every XCD gets
+    // the same mix of cheap and expensive regions. xcdBands (PT_XCD_BANDS=1) instead gives each XCD one
+    // contiguous band so its L2 holds only that band's geometry; measured: no gain on the 263 k scene
+    // (secondary rays leave the band at once), -14 % / -9 % on the 82 k scene / Cornell (bands differ
+    // in cost and a static 1/8 split cannot rebalance). Kept as the A/B switch.
+    int vb = blockIdx.x;
+    if (P.xcdBands) {
+        const int nB = gridDim.x, q = nB >> 3, r = nB & 7, x = vb & 7;
+        vb = x * q + (x < r ? x : r) + (vb >> 3);
+    }
+    const int lt = vb * 4 + wave;
     if (lt >= P.tileCount) return;
     const int tile = P.tileFirst + lt * P.tileStride;
     const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
