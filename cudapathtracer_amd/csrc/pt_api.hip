@@ -55,13 +55,15 @@ struct DevBuf {
 struct pt_scene {
     int device = 0;
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
-    DevBuf rng, spill, tilebuf, colors, pixcnt;       // work buffers, grown on demand
+    DevBuf rng, spill, tilebuf, colors, pixcnt, cursor; // work buffers, grown on demand
     DevBuf wfState, wfCtl, wfCtr, wfSpill;            // wavefront variant
     int variant = 0;                                  // 0 megakernel, 1 wavefront (pt_set_variant)
     int numCU = 256;
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
+    bool lptPrio = true;         // PT_LPT_PRIO=0: no issue-priority steering at the end of the frame (A/B)
+    bool persistent = true;      // PT_PERSISTENT=0: one tile per wave, workgroups launched per 4 tiles (A/B)
     bool xcdBands = false;       // PT_XCD_BANDS=1: one contiguous band of tiles per XCD (A/B; loses to interleaving)
     bool deferShadow = false;    // PT_DEFER_SHADOW=1: megakernel traces shadow + extension ray as a pair (A/B; slower)
     float lastKernelMs = 0.0f;
@@ -86,7 +88,7 @@ int pt_device_count(void) {
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
     DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals,
-                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
+                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->cursor, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -275,6 +277,8 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
+    if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = (e[0] != '0');
+    if (const char* e = getenv("PT_PERSISTENT")) s->persistent = (e[0] != '0');
     if (const char* e = getenv("PT_XCD_BANDS")) s->xcdBands = (e[0] == '1');
     {
         hipDeviceProp_t prop;
@@ -389,6 +393,13 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
+    P.tileCursor = nullptr; P.gridBlocks = 0; P.lptPrio = s->lptPrio ? 1 : 0;
+    if (s->persistent && !s->xcdBands) {
+        if (int r = s->cursor.ensure(256)) return r;
+        HIP_OK(hipMemsetAsync(s->cursor.p, 0, 4 * sizeof(int), stream));
+        P.tileCursor = (int*)s->cursor.p;
+        P.gridBlocks = s->numCU * 4;               // 16 waves per CU: 128 VGPRs (PT_MIN_WAVES = 4) and <= 40 KB LDS per workgroup
+    }
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;

@@ -116,8 +116,20 @@ megakernel(KParams P) {
         const int nB = gridDim.x, q = nB >> 3, r = nB & 7, x = vb & 7;
         vb = x * q + (x < r ? x : r) + (vb >> 3);
     }
-    const int lt = vb * 4 + wave;
-    if (lt >= P.tileCount) return;
+    // Persistent waves (P.tileCursor != null): the grid only fills the chip and every wave takes its next
+    // tile from one atomic cursor, so a wave slot is never parked behind the slowest of four sibling
+    // waves or behind workgroup launch; tiles are independent, so the order does not reach the image.
+    for (bool first = true;; first = false) {
+    int lt;
+    if (P.tileCursor) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(P.tileCursor, 1);
+        lt = __builtin_amdgcn_readfirstlane(t);
+    } else {
+        if (!first) break;
+        lt = vb * 4 + wave;
+    }
+    if (lt >= P.tileCount) break;
     const int tile = P.tileFirst + lt * P.tileStride;
     const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
     const bool inImage = (x < P.w) && (y < P.h);
@@ -149,12 +161,40 @@ megakernel(KParams P) {
 #ifdef PT_STAMPS
     unsigned long long stamp[2] = {0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long wall0 = wall_clock64();     // device-wide 100 MHz clock: slot occupancy (tools/stamps.py)
 #endif
     // Every iteration: one logic step per lane (finish the previous bounce's NEE, shade the hit,
     // regenerate if the path ended), then one traversal round for the rays the logic produced. A
     // lane whose path ended starts its pixel's next sample in the same step, so the wave keeps 64
     // live rays until the pixels run out of samples; a ballot ends the wave.
+    // Longest-remaining-first inside a SIMD (P.lptPrio). Once the tile cursor is exhausted no slot gets
+    // new work and the kernel ends with its slowest pixel chain (a pixel's samples are one sequential RNG
+    // stream, so a chain cannot be split); a wave that is alone on its SIMD runs latency-bound, far below
+    // the SIMD's throughput. Waves publish their remaining samples; a wave with more left than the mean
+    // of the waves still running raises its issue priority (s_setprio), so the long chains advance at
+    // near single-wave speed while the short ones fill the gaps — the image does not depend on it.
+    int itc = 0, myRem = 0;
+    const bool lpt = P.tileCursor != nullptr && P.lptPrio != 0;
+    if (lpt && lane == 0) { atomicAdd(&P.tileCursor[2], 1); atomicAdd(&P.tileCursor[1], P.spp); }
+    if (lpt) myRem = P.spp;
     while (true) {
+        if (lpt && ((++itc) & 31) == 0) {
+            int rem = samplesLeft + ((ps.flags & kInPath) ? 1 : 0);
+            for (int o = 32; o; o >>= 1) rem = max(rem, __shfl_xor(rem, o));
+            if (lane == 0 && rem != myRem) atomicAdd(&P.tileCursor[1], rem - myRem);
+            myRem = rem;
+            const volatile int* q = P.tileCursor;
+            int prio = 0;
+            if (q[0] >= P.tileCount) {
+                const long long sum = q[1], act = q[2] > 0 ? q[2] : 1;
+                const long long r10 = 10ll * rem * act;
+                prio = r10 >= 13 * sum ? 3 : (r10 >= 11 * sum ? 2 : (r10 >= 9 * sum ? 1 : 0));
+            }
+            if (prio == 3) __builtin_amdgcn_s_setprio(3);
+            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         if (DEFER) apply_pending(ps, thr, acc);
         if (ps.flags & kInPath) {
             bool done = path_bounce<INTEG, COUNT, DEFER>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
@@ -175,8 +215,18 @@ megakernel(KParams P) {
         PT_STAMP(1);
     }
 
+    if (lpt) {
+        if (lane == 0) { atomicAdd(&P.tileCursor[1], -myRem); atomicAdd(&P.tileCursor[2], -1); }
+        __builtin_amdgcn_s_setprio(0);
+    }
 #ifdef PT_STAMPS
-    if (P.totals && lane == 0) for (int k = 0; k < 2; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
+    if (P.totals && lane == 0) {
+        for (int k = 0; k < 2; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
+        const unsigned long long wall1 = wall_clock64();
+        atomicAdd(&P.totals[10], wall1 - wall0);             // sum of wave lifetimes
+        atomicMax(&P.totals[11], ~wall0);                     // ~(earliest start)
+        atomicMax(&P.totals[12], wall1);                      // latest end
+    }
 #endif
     if (inImage) P.out[(size_t)lt * 64 + lane] = make_float4(acc.x, acc.y, acc.z, acc4.w);
     {
@@ -196,6 +246,7 @@ megakernel(KParams P) {
             wave_add_total(P.totals, 6, c.draws); wave_add_total(P.totals, 7, c.iters);
         }
     }
+    }   // next tile
 }
 
 // -------------------------------------------------------------------------------------------
@@ -338,7 +389,9 @@ hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w,
 
 hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const KParams& P, hipStream_t stream) {
     if (P.tileCount <= 0) return hipSuccess;
-    dim3 grid(megakernel_blocks(P.tileCount)), block(256);
+    int nBlocks = megakernel_blocks(P.tileCount);
+    if (P.tileCursor && P.gridBlocks > 0) nBlocks = std::min(nBlocks, P.gridBlocks);
+    dim3 grid(nBlocks), block(256);
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
     if (integrator == 2) {
         if (count) hipLaunchKernelGGL((megakernel<2, true, false>), grid, block, lds, stream, P);

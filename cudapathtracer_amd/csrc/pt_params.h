@@ -31,6 +31,10 @@ struct KParams {
     uint32_t* pixCounters;         // [tile][8][64] or null
     unsigned long long* totals;    // 8 x u64 or null
     int32_t* spill;                // [wave slot][entry][64] or null
+    int gridBlocks;                // persistent waves: workgroups that fill the chip (numCU x resident workgroups per CU)
+    int* tileCursor;               // persistent waves: [0] next local tile to hand out, [1] sum of remaining samples of the waves running,
+                                   // [2] waves running (zeroed before the launch); null = one tile per wave
+    int lptPrio;                   // longest-remaining-first issue priority once the cursor is exhausted
 };
 
 struct TileSpan { int first, stride, count, tilesX; };

@@ -14,7 +14,14 @@ tiles = torch.zeros(api.n_tiles(1920, 1080), 64, 4, device="cuda")
 sc.reset_counters()
 sc.render_tiles_device(hs.camera(), 1920, 1080, spp, 8, tiles.data_ptr(), count_work=True)
 torch.cuda.synchronize()
-st = sc.debug_stamps(); tot = sum(st.values()) or 1
+st = sc.debug_stamps()
+life, nstart, end = st.pop("shade_pre"), st.pop("shadow"), st.pop("shade_post"); st.pop("loop")
+span = end - ((~nstart) & (2**64 - 1))
+if span > 0:
+    slots = 256 * 16
+    print("wave lifetimes %.3f s-slots, span %.3f ms, mean resident waves %.0f of %d (%.1f %%)" %
+          (life / 1e8, span / 1e5, life / span, slots, 100.0 * life / span / slots))
+tot = sum(st.values()) or 1
 print("kernel ms", sc.last_kernel_ms())
 for k, v in st.items(): print("%-11s %6.2f %%" % (k, 100.0 * v / tot))
 print(sc.counters())
