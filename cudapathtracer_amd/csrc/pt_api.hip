@@ -55,14 +55,17 @@ struct DevBuf {
 struct pt_scene {
     int device = 0;
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
-    DevBuf rng, spill, tilebuf, colors, pixcnt, cursor; // work buffers, grown on demand
+    DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
     DevBuf wfState, wfCtl, wfCtr, wfSpill;            // wavefront variant
     int variant = 0;                                  // 0 megakernel, 1 wavefront (pt_set_variant)
     int numCU = 256;
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
-    bool lptPrio = true;         // PT_LPT_PRIO=0: no issue-priority steering at the end of the frame (A/B)
+    int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
+    bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
+    int sliceIters = 512;        // PT_SLICE_ITERS: time slice of the tile queue once no fresh tile is left (0 = off)
+    int lptPrio = 2;             // PT_LPT_PRIO: 0 no issue-priority steering, 1 once no fresh tile is left, 2 always (A/B)
     bool persistent = true;      // PT_PERSISTENT=0: one tile per wave, workgroups launched per 4 tiles (A/B)
     bool xcdBands = false;       // PT_XCD_BANDS=1: one contiguous band of tiles per XCD (A/B; loses to interleaving)
     bool deferShadow = false;    // PT_DEFER_SHADOW=1: megakernel traces shadow + extension ray as a pair (A/B; slower)
@@ -70,6 +73,8 @@ struct pt_scene {
     bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+
+static int queue_error(pt_scene* s);
 
 extern "C" {
 
@@ -88,7 +93,7 @@ int pt_device_count(void) {
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
     DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals,
-                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->cursor, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
+                     &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->queue, &s->left, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -277,7 +282,10 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     }
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
-    if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = (e[0] != '0');
+    if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
+    if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
+    if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
+    if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = atoi(e);     // 0 off, 1 once no fresh tile is left, 2 always
     if (const char* e = getenv("PT_PERSISTENT")) s->persistent = (e[0] != '0');
     if (const char* e = getenv("PT_XCD_BANDS")) s->xcdBands = (e[0] == '1');
     {
@@ -393,11 +401,14 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
-    P.tileCursor = nullptr; P.gridBlocks = 0; P.lptPrio = s->lptPrio ? 1 : 0;
+    P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
+    P.lptPrio = s->lptPrio; P.sliceIters = s->sliceIters; P.schedMask = s->schedMask; P.sliceAlways = s->sliceAlways ? 1 : 0;
     if (s->persistent && !s->xcdBands) {
-        if (int r = s->cursor.ensure(256)) return r;
-        HIP_OK(hipMemsetAsync(s->cursor.p, 0, 4 * sizeof(int), stream));
-        P.tileCursor = (int*)s->cursor.p;
+        int cap = 256;
+        while (cap < t.count) cap <<= 1;
+        if (int r = s->queue.ensure((size_t)(8 + 2 * cap) * sizeof(int))) return r;
+        if (int r = s->left.ensure((size_t)t.count * 64 * sizeof(int))) return r;
+        P.queue = (int*)s->queue.p; P.queueMask = cap - 1; P.left = (int*)s->left.p;
         P.gridBlocks = s->numCU * 4;               // 16 waves per CU: 128 VGPRs (PT_MIN_WAVES = 4) and <= 40 KB LDS per workgroup
     }
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
@@ -494,6 +505,7 @@ int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, 
     }
     if (int r = launch_on_colors(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, s->colors.p, dpc, true)) return r;
     HIP_OK(hipMemcpy(out, s->colors.p, px * sizeof(float4), hipMemcpyDeviceToHost));
+    if (int r = queue_error(s)) return r;
     if (outCounters) {
         std::vector<uint32_t> tmp((size_t)t.count * 512);
         HIP_OK(hipMemcpy(tmp.data(), dpc, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -538,11 +550,22 @@ int pt_debug_stamps(pt_scene* s, unsigned long long* out6) {
     return 0;
 }
 
+// The tile queue's waits are bounded (pt_kernels.hip); a wait that ran out leaves q[3] != 0 and an
+// unfinished frame. Read where the host waits for the kernel anyway.
+static int queue_error(pt_scene* s) {
+    if (!s->queue.p || s->variant != 0) return 0;
+    int q[4] = {0, 0, 0, 0};
+    if (hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess) return fail(-2, "tile queue read-back failed");
+    if (q[3] != 0) return fail(-4, "megakernel tile queue timed out (code %d, %d tiles finished): the frame is incomplete", q[3], q[2]);
+    return 0;
+}
+
 float pt_last_kernel_ms(pt_scene* s) {
     if (!s) return -1.0f;
     if (s->evPending) {                                // waits for the last megakernel launch to finish
         if (hipEventSynchronize(s->ev1) != hipSuccess || hipEventElapsedTime(&s->lastKernelMs, s->ev0, s->ev1) != hipSuccess) return -1.0f;
         s->evPending = false;
+        if (queue_error(s)) return -1.0f;
     }
     return s->lastKernelMs;
 }

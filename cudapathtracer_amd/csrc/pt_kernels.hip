@@ -95,6 +95,73 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
     ps.flags &= ~kInPath;
 }
 
+// ---- tile queue of the persistent megakernel -------------------------------------------------
+// A bounded multi-producer / multi-consumer ring in global memory:
+//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] error, q[4] sum of remaining samples
+//   of the tiles being worked on, q[5] waves working; from q + 8: cap 64-bit slots {sequence, item}
+//   (cap = mask + 1 >= tiles; Vyukov's scheme: slot p%cap holds sequence p+1 when push p is in it, and
+//   p+cap once pop p has taken it). It starts holding every tile once (kFreshBit). A wave that yields a
+//   tile at the end of a time slice pushes it back; a tile is in the ring at most once, so it cannot overflow.
+// Memory model. A yielded tile's state (RNG, accumulator, samples left) moves between waves on different
+// XCDs, whose L2s are not coherent with each other. Fences at agent scope would do it, but on gfx950 they
+// write back / invalidate the whole L2 each time — measured 3x slower on the 263 k-triangle scene. Instead
+// every access to queue words and tile state inside the kernel is a relaxed agent-scope atomic (sc1: served
+// at the memory side, never from a possibly stale cache line), slot and item travel in ONE 64-bit word, and
+// "state before the queue entry" is the wave waiting for its own stores (workgroup-scope release = s_waitcnt).
+// Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
+// surface as an error code, never as a hung GPU.
+constexpr int kFreshBit = 1 << 30;
+constexpr unsigned long long kQueueTimeout = 3000000000ull;            // 30 s of the 100 MHz wall clock
+#define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
+PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
+    int item = -1;
+    if (lane == 0) {
+        const unsigned pos = atomicAdd((unsigned*)&q[0], 1u);
+        unsigned long long* slot = queue_slot(q, mask, pos);
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spin = 0;; spin++) {
+            const unsigned long long v = PT_QLOAD(slot);
+            if ((unsigned)v == pos + 1u) {
+                item = (int)(v >> 32);
+                PT_QSTORE(slot, (unsigned long long)(pos + (unsigned)mask + 1u));
+                break;
+            }
+            if (!mayWait) break;                                                // without time slices nothing is ever pushed
+            if ((spin & 7) == 0) {
+                if (PT_QLOAD(&q[2]) >= nTiles || PT_QLOAD(&q[3]) != 0) break;   // frame finished, or somebody gave up
+                if (wall_clock64() - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 1); break; }
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(item);
+}
+PT_DEV void queue_push(int* q, int mask, int item, int lane) {
+    if (lane == 0) {
+        const unsigned pos = atomicAdd((unsigned*)&q[1], 1u);
+        unsigned long long* slot = queue_slot(q, mask, pos);
+        const unsigned long long t0 = wall_clock64();
+        while ((unsigned)PT_QLOAD(slot) != pos) {
+            if (PT_QLOAD(&q[3]) != 0) return;
+            if (wall_clock64() - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 2); return; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        PT_QSTORE(slot, ((unsigned long long)(unsigned)item << 32) | (unsigned long long)(pos + 1u));
+    }
+}
+__global__ void queue_init_kernel(int* q, int mask, int nTiles) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { q[0] = 0; q[1] = nTiles; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0; q[6] = 0; q[7] = 0; }
+    if (i <= mask)
+        ((unsigned long long*)(q + 8))[i] = i < nTiles ? (((unsigned long long)(unsigned)(i | kFreshBit) << 32) | (unsigned long long)(i + 1)) : (unsigned long long)i;
+}
+// Tile state words: plain accesses when one wave owns the tile for the whole kernel, memory-side ones when
+// tiles can change hands (see above).
+PT_DEV uint32_t state_load(const uint32_t* p, bool shared) { return shared ? PT_QLOAD(p) : *p; }
+PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_QSTORE(p, v); else *p = v; }
+
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h.
 template <int INTEG, bool COUNT, bool DEFER>
 __global__ void __launch_bounds__(256)
@@ -116,15 +183,17 @@ megakernel(KParams P) {
         const int nB = gridDim.x, q = nB >> 3, r = nB & 7, x = vb & 7;
         vb = x * q + (x < r ? x : r) + (vb >> 3);
     }
-    // Persistent waves (P.tileCursor != null): the grid only fills the chip and every wave takes its next
-    // tile from one atomic cursor, so a wave slot is never parked behind the slowest of four sibling
-    // waves or behind workgroup launch; tiles are independent, so the order does not reach the image.
+    // Persistent waves (P.queue != null): the grid only fills the chip and every wave takes its next tile
+    // from the queue, so a wave slot is never parked behind the slowest of four sibling waves or behind
+    // workgroup launch; tiles are independent, so the order does not reach the image.
     for (bool first = true;; first = false) {
     int lt;
-    if (P.tileCursor) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(P.tileCursor, 1);
-        lt = __builtin_amdgcn_readfirstlane(t);
+    bool fresh = true;
+    if (P.queue) {
+        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0);
+        if (item < 0) break;
+        fresh = (item & kFreshBit) != 0;
+        lt = item & ~kFreshBit;
     } else {
         if (!first) break;
         lt = vb * 4 + wave;
@@ -143,17 +212,24 @@ megakernel(KParams P) {
     ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + 4 * kStackLds * 256) + wave * (kMediumMax * 64) + lane;
 
     PathState ps;
+    const bool shared = P.queue != nullptr && !COUNT && P.sliceIters > 0;       // tiles may change hands
     {
         const uint32_t* r = P.rng + (size_t)lt * 384 + lane;
-        ps.rng.v0 = r[0]; ps.rng.v1 = r[64]; ps.rng.v2 = r[128]; ps.rng.v3 = r[192]; ps.rng.v4 = r[256]; ps.rng.d = r[320];
+        ps.rng.v0 = state_load(r, shared); ps.rng.v1 = state_load(r + 64, shared); ps.rng.v2 = state_load(r + 128, shared);
+        ps.rng.v3 = state_load(r + 192, shared); ps.rng.v4 = state_load(r + 256, shared); ps.rng.d = state_load(r + 320, shared);
     }
     ps.o = v3(0.0f); ps.d = v3(0.0f); ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
     ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps; ps.depth = 0; ps.guard = 0; ps.msTop = 1; ps.flags = 0;
     ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; ps.LiFinish = v3(0.0f);
-    float4 acc4 = P.out[(size_t)lt * 64 + lane];
+    float4 acc4;
+    {
+        const uint32_t* o = (const uint32_t*)(P.out + (size_t)lt * 64 + lane);
+        acc4 = make_float4(__uint_as_float(state_load(o, shared)), __uint_as_float(state_load(o + 1, shared)),
+                           __uint_as_float(state_load(o + 2, shared)), __uint_as_float(state_load(o + 3, shared)));
+    }
     V3 acc = v3(acc4.x, acc4.y, acc4.z);
     Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
-    int samplesLeft = inImage ? P.spp : 0;
+    int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
     auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, kStackLds>(S, SC, ro, wi, maxt, st, c); };
@@ -173,27 +249,43 @@ megakernel(KParams P) {
     // the SIMD's throughput. Waves publish their remaining samples; a wave with more left than the mean
     // of the waves still running raises its issue priority (s_setprio), so the long chains advance at
     // near single-wave speed while the short ones fill the gaps — the image does not depend on it.
-    int itc = 0, myRem = 0;
-    const bool lpt = P.tileCursor != nullptr && P.lptPrio != 0;
-    if (lpt && lane == 0) { atomicAdd(&P.tileCursor[2], 1); atomicAdd(&P.tileCursor[1], P.spp); }
-    if (lpt) myRem = P.spp;
+    // Time slices (P.sliceIters). With no fresh tile left, what each SIMD still has to do is whatever its
+    // four waves happen to hold, and the sums differ (measured: the worst SIMD carries ~1.3x the mean when
+    // every slot holds exactly one tile, the 8-GPU case). So from then on a wave works on a tile for
+    // sliceIters bounce iterations, lets its lanes finish the paths in flight (no new samples), writes the
+    // tile's state back (RNG, accumulator, samples left per pixel) and queues it again; the next free wave —
+    // on any SIMD — continues it. The per-pixel streams continue exactly where they stopped.
+    int itc = 0, myRem = 0, sliceEnd = 0x7fffffff;
+    bool stopStarting = false;
+    const bool lpt = P.queue != nullptr && P.lptPrio != 0;
+    if (lpt) {
+        myRem = samplesLeft;
+        for (int o = 32; o; o >>= 1) myRem = max(myRem, __shfl_xor(myRem, o));
+        if (lane == 0) { atomicAdd(&P.queue[5], 1); atomicAdd(&P.queue[4], myRem); }
+    }
     while (true) {
-        if (lpt && ((++itc) & 31) == 0) {
-            int rem = samplesLeft + ((ps.flags & kInPath) ? 1 : 0);
-            for (int o = 32; o; o >>= 1) rem = max(rem, __shfl_xor(rem, o));
-            if (lane == 0 && rem != myRem) atomicAdd(&P.tileCursor[1], rem - myRem);
-            myRem = rem;
-            const volatile int* q = P.tileCursor;
-            int prio = 0;
-            if (q[0] >= P.tileCount) {
-                const long long sum = q[1], act = q[2] > 0 ? q[2] : 1;
-                const long long r10 = 10ll * rem * act;
-                prio = r10 >= 13 * sum ? 3 : (r10 >= 11 * sum ? 2 : (r10 >= 9 * sum ? 1 : 0));
+        if (P.queue && ((++itc) & P.schedMask) == 0) {
+            const bool exhausted = PT_QLOAD(&P.queue[0]) >= P.tileCount;
+            if (!COUNT && P.sliceIters > 0 && (exhausted || P.sliceAlways)) {
+                if (sliceEnd == 0x7fffffff) sliceEnd = itc + P.sliceIters;
+                else if (itc >= sliceEnd) stopStarting = true;
             }
-            if (prio == 3) __builtin_amdgcn_s_setprio(3);
-            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-            else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
+            if (lpt) {
+                int rem = samplesLeft + ((ps.flags & kInPath) ? 1 : 0);
+                for (int o = 32; o; o >>= 1) rem = max(rem, __shfl_xor(rem, o));
+                if (lane == 0 && rem != myRem) atomicAdd(&P.queue[4], rem - myRem);
+                myRem = rem;
+                int prio = 0;
+                if (exhausted || P.lptPrio == 2) {
+                    const long long sum = PT_QLOAD(&P.queue[4]), a = PT_QLOAD(&P.queue[5]), act = a > 0 ? a : 1;
+                    const long long r10 = 10ll * rem * act;
+                    prio = r10 >= 13 * sum ? 3 : (r10 >= 11 * sum ? 2 : (r10 >= 9 * sum ? 1 : 0));
+                }
+                if (prio == 3) __builtin_amdgcn_s_setprio(3);
+                else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+                else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
         }
         if (DEFER) apply_pending(ps, thr, acc);
         if (ps.flags & kInPath) {
@@ -201,7 +293,7 @@ megakernel(KParams P) {
             if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
             if (done) path_finish(ps, acc, DEFER);
         }
-        while (!(ps.flags & kInPath) && samplesLeft > 0) {
+        while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
             samplesLeft--;
             path_begin<COUNT>(P.cam, ps, ms, x, y, c);
             if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, DEFER);
@@ -216,7 +308,7 @@ megakernel(KParams P) {
     }
 
     if (lpt) {
-        if (lane == 0) { atomicAdd(&P.tileCursor[1], -myRem); atomicAdd(&P.tileCursor[2], -1); }
+        if (lane == 0) { atomicAdd(&P.queue[4], -myRem); atomicAdd(&P.queue[5], -1); }
         __builtin_amdgcn_s_setprio(0);
     }
 #ifdef PT_STAMPS
@@ -228,10 +320,24 @@ megakernel(KParams P) {
         atomicMax(&P.totals[12], wall1);                      // latest end
     }
 #endif
-    if (inImage) P.out[(size_t)lt * 64 + lane] = make_float4(acc.x, acc.y, acc.z, acc4.w);
+    if (inImage) {
+        uint32_t* o = (uint32_t*)(P.out + (size_t)lt * 64 + lane);
+        state_store(o, __float_as_uint(acc.x), shared); state_store(o + 1, __float_as_uint(acc.y), shared);
+        state_store(o + 2, __float_as_uint(acc.z), shared); state_store(o + 3, __float_as_uint(acc4.w), shared);
+    }
     {
         uint32_t* r = P.rng + (size_t)lt * 384 + lane;
-        r[0] = ps.rng.v0; r[64] = ps.rng.v1; r[128] = ps.rng.v2; r[192] = ps.rng.v3; r[256] = ps.rng.v4; r[320] = ps.rng.d;
+        state_store(r, ps.rng.v0, shared); state_store(r + 64, ps.rng.v1, shared); state_store(r + 128, ps.rng.v2, shared);
+        state_store(r + 192, ps.rng.v3, shared); state_store(r + 256, ps.rng.v4, shared); state_store(r + 320, ps.rng.d, shared);
+    }
+    if (P.queue) {
+        int left = samplesLeft;
+        for (int o = 32; o; o >>= 1) left = max(left, __shfl_xor(left, o));
+        if (left > 0) {                                // yielded: somebody else continues this tile
+            state_store((uint32_t*)P.left + (size_t)lt * 64 + lane, (uint32_t)samplesLeft, true);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's state stores have landed before the entry appears
+            queue_push(P.queue, P.queueMask, lt, lane);
+        } else if (lane == 0) atomicAdd(&P.queue[2], 1);
     }
     if (COUNT) {
         if (P.pixCounters) {
@@ -390,7 +496,10 @@ hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w,
 hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const KParams& P, hipStream_t stream) {
     if (P.tileCount <= 0) return hipSuccess;
     int nBlocks = megakernel_blocks(P.tileCount);
-    if (P.tileCursor && P.gridBlocks > 0) nBlocks = std::min(nBlocks, P.gridBlocks);
+    if (P.queue && P.gridBlocks > 0) {
+        nBlocks = std::min(nBlocks, P.gridBlocks);
+        hipLaunchKernelGGL(queue_init_kernel, dim3((P.queueMask + 256) / 256), dim3(256), 0, stream, P.queue, P.queueMask, P.tileCount);
+    }
     dim3 grid(nBlocks), block(256);
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
     if (integrator == 2) {

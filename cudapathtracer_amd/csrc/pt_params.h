@@ -32,9 +32,13 @@ struct KParams {
     unsigned long long* totals;    // 8 x u64 or null
     int32_t* spill;                // [wave slot][entry][64] or null
     int gridBlocks;                // persistent waves: workgroups that fill the chip (numCU x resident workgroups per CU)
-    int* tileCursor;               // persistent waves: [0] next local tile to hand out, [1] sum of remaining samples of the waves running,
-                                   // [2] waves running (zeroed before the launch); null = one tile per wave
-    int lptPrio;                   // longest-remaining-first issue priority once the cursor is exhausted
+    int* queue;                    // persistent waves: tile queue (pt_kernels.hip: queue_pop / queue_push); null = one tile per wave
+    int queueMask;                 // ring capacity - 1 (power of two >= tileCount)
+    int sliceIters;                // bounce iterations a wave keeps a tile once no fresh tile is left; 0 = until it is finished
+    int sliceAlways;               // 1: slices from the first tile on (round-robin over all tiles), 0: only once no fresh tile is left
+    int* left;                     // [tile][64] samples left per pixel of a yielded tile
+    int schedMask;                 // the wave looks at the queue / its priority every schedMask + 1 iterations (31)
+    int lptPrio;                   // longest-remaining-first issue priority once no fresh tile is left
 };
 
 struct TileSpan { int first, stride, count, tilesX; };

@@ -171,6 +171,24 @@ def test_render_matches_golden(api, gpu_ready, case):
     assert tot["rays_closest"] == int(g["counters"][..., 0].sum()) and tot["tri_tests"] == int(g["counters"][..., 4].sum())
 
 
+@pytest.mark.parametrize("sched", [("0", "31", "1"), ("4", "3", "2"), ("8", "7", "0"), ("512", "31", "2")])
+def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
+    """The timed (counters-off) kernel with its scheduling machinery driven hard: tiles are yielded after
+    4-8 bounce iterations, queued again and continued by whichever wave is free (production: 256), with and
+    without issue-priority steering. Scheduling must not reach the image: golden colours bit for bit."""
+    monkeypatch.setenv("PT_SLICE_ITERS", sched[0]); monkeypatch.setenv("PT_SCHED_MASK", sched[1]); monkeypatch.setenv("PT_LPT_PRIO", sched[2])
+    for case in CASES:
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        sc = api.Scene(hs)
+        w, h = int(g["w"]), int(g["h"])
+        for _ in range(2):                                  # second launch: queue re-initialised
+            col, _ = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]))
+            assert_bits_equal(col, g["colors"], case)
+        assert sc.last_kernel_ms() > 0.0                    # also reads the queue's error word
+        sc.close()
+
+
 @pytest.mark.parametrize("integrator", [0, 2])
 def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integrator):
     from cudapathtracer_amd import scenes
