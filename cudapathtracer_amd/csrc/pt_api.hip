@@ -64,6 +64,8 @@ struct pt_scene {
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
+    bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
+    int nTrisPacked = 0;
     int sliceIters = 512;        // PT_SLICE_ITERS: time slice of the tile queue once no fresh tile is left (0 = off)
     int lptPrio = 2;             // PT_LPT_PRIO: 0 no issue-priority steering, 1 once no fresh tile is left, 2 always (A/B)
     bool persistent = true;      // PT_PERSISTENT=0: one tile per wave, workgroups launched per 4 tiles (A/B)
@@ -267,6 +269,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     s->ds.nLights = d->n_lights; s->ds.nTris = nT;
     s->ds.stackSpill = std::max(0, stackNeed - kStackLds);
     // scene cache: everything if it fits the LDS budget, else only the top of the (breadth-first) tree
+    s->nTrisPacked = nT;
     if ((size_t)nInternal * 64 + (size_t)nT * 48 <= (size_t)kCacheBytes) { s->cacheNodes = nInternal; s->cacheTris = nT; }
     else { s->cacheNodes = std::min(nInternal, kCacheBytes / 64); s->cacheTris = 0; }
     return 0;
@@ -283,6 +286,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
     if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
+    if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
     if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = atoi(e);     // 0 off, 1 once no fresh tile is left, 2 always
@@ -401,6 +405,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
+    P.onchip = (s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0) ? 1 : 0;
     P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
     P.lptPrio = s->lptPrio; P.sliceIters = s->sliceIters; P.schedMask = s->schedMask; P.sliceAlways = s->sliceAlways ? 1 : 0;
     if (s->persistent && !s->xcdBands) {

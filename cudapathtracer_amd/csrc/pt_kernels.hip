@@ -162,8 +162,9 @@ __global__ void queue_init_kernel(int* q, int mask, int nTiles) {
 PT_DEV uint32_t state_load(const uint32_t* p, bool shared) { return shared ? PT_QLOAD(p) : *p; }
 PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_QSTORE(p, v); else *p = v; }
 
-// INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h.
-template <int INTEG, bool COUNT, bool DEFER>
+// INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
+// scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP>
 __global__ void __launch_bounds__(256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
@@ -232,7 +233,7 @@ megakernel(KParams P) {
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, kStackLds>(S, SC, ro, wi, maxt, st, c); };
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, kStackLds, ONCHIP>(S, SC, ro, wi, maxt, st, c); };
 
 #ifdef PT_STAMPS
     unsigned long long stamp[2] = {0, 0};
@@ -303,7 +304,7 @@ megakernel(KParams P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, kStackLds>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
-        else if (hasExt) trace_closest<COUNT, kStackLds>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
+        else if (hasExt) trace_closest<COUNT, kStackLds, ONCHIP>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
         PT_STAMP(1);
     }
 
@@ -502,16 +503,12 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
     }
     dim3 grid(nBlocks), block(256);
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
-    if (integrator == 2) {
-        if (count) hipLaunchKernelGGL((megakernel<2, true, false>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((megakernel<2, false, false>), grid, block, lds, stream, P);
-    } else if (syncShadow) {
-        if (count) hipLaunchKernelGGL((megakernel<0, true, false>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((megakernel<0, false, false>), grid, block, lds, stream, P);
-    } else {
-        if (count) hipLaunchKernelGGL((megakernel<0, true, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((megakernel<0, false, true>), grid, block, lds, stream, P);
-    }
+#define PT_LAUNCH_MK(I, C, D, O) hipLaunchKernelGGL((megakernel<I, C, D, O>), grid, block, lds, stream, P)
+#define PT_LAUNCH_MK2(I, D) do { if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, D, true); else PT_LAUNCH_MK(I, true, D, false); } \
+                                 else { if (P.onchip) PT_LAUNCH_MK(I, false, D, true); else PT_LAUNCH_MK(I, false, D, false); } } while (0)
+    if (integrator == 2) PT_LAUNCH_MK2(2, false);
+    else if (syncShadow) PT_LAUNCH_MK2(0, false);
+    else { if (count) PT_LAUNCH_MK(0, true, true, false); else PT_LAUNCH_MK(0, false, true, false); }
     return hipGetLastError();
 }
 

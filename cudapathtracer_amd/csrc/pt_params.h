@@ -25,6 +25,7 @@ struct KParams {
     int w, h, spp, maxDepth, useMIS;
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
+    int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)
     uint32_t* rng;                 // [tile][6][64]
     float4* out;                   // [tile][64], += semantics

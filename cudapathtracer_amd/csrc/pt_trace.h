@@ -49,14 +49,17 @@ struct Stack {
     lds_i32* lds;
     int32_t* spill;
     int sp;
+    // ONCHIP: the host has checked that the tree never needs more than N entries (no spill path).
+    template <bool ONCHIP = false>
     PT_DEV void push(int32_t v) {
-        if (sp < N) lds[sp * 64] = v; else spill[(sp - N) * 64] = v;
+        if (ONCHIP || sp < N) lds[sp * 64] = v; else spill[(sp - N) * 64] = v;
         sp++;
     }
+    template <bool ONCHIP = false>
     PT_DEV int32_t pop() {
         sp--;
         int32_t v;
-        if (sp < N) v = lds[sp * 64]; else v = spill[(sp - N) * 64];
+        if (ONCHIP || sp < N) v = lds[sp * 64]; else v = spill[(sp - N) * 64];
         return v;
     }
 };
@@ -92,10 +95,13 @@ PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u,
     return ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f)) && t > 0.0f;
 }
 
+// ONCHIP (template flag of the traversals): every PNode and PTri is in the LDS scene cache and the stack
+// fits its LDS part — Cornell-class scenes. The loops then carry no global-memory path and no branch for it.
 struct NodeData { f4v a, b, c, d; };
+template <bool ONCHIP = false>
 PT_DEV NodeData load_node(const DeviceScene& S, const SceneCache& C, int32_t i) {
     NodeData n;
-    if (i < C.nNodes) {
+    if (ONCHIP || i < C.nNodes) {
         lds_cf4* p = C.nodes + i * 4;
         n.a = p[0]; n.b = p[1]; n.c = p[2]; n.d = p[3];
     } else {
@@ -105,9 +111,10 @@ PT_DEV NodeData load_node(const DeviceScene& S, const SceneCache& C, int32_t i) 
     return n;
 }
 struct TriData { f4v a, b, e; };
+template <bool ONCHIP = false>
 PT_DEV TriData load_tri(const DeviceScene& S, const SceneCache& C, int32_t i) {
     TriData t;
-    if (C.nTris) {                         // wave-uniform
+    if (ONCHIP || C.nTris) {               // wave-uniform
         lds_cf4* p = C.tris + i * 3;
         t.a = p[0]; t.b = p[1]; t.e = p[2];
     } else {
@@ -118,9 +125,9 @@ PT_DEV TriData load_tri(const DeviceScene& S, const SceneCache& C, int32_t i) {
 }
 
 // One internal-node step shared by both traversals: returns the next ref to visit.
-template <bool COUNT, int N>
+template <bool COUNT, int N, bool ONCHIP = false>
 PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c) {
-    NodeData n = load_node(S, C, cur);
+    NodeData n = load_node<ONCHIP>(S, C, cur);
     if (COUNT) { c.pops++; c.boxes += 2; }
     float tL, tR;
     bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
@@ -128,16 +135,16 @@ PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V
     int32_t left = f2i(n.d.x), right = f2i(n.d.y);
     if (hL && hR) {
         bool leftNear = tL < tR;
-        st.push(leftNear ? right : left);
+        st.template push<ONCHIP>(leftNear ? right : left);
         return leftNear ? left : right;
     }
     if (hL) return left;
     if (hR) return right;
-    return st.sp > 0 ? st.pop() : kRefNone;
+    return st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
 }
 
 // BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
-template <bool COUNT, int N>
+template <bool COUNT, int N, bool ONCHIP = false>
 PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float min_t = 3.402823466e+38f;
@@ -146,13 +153,13 @@ PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d,
     int32_t cur = S.rootRef;
     if (COUNT) c.raysClosest++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+        while (cur >= 0) cur = descend<COUNT, N, ONCHIP>(S, C, cur, o, inv, st, c);
         if (cur == kRefNone) break;
         if (COUNT) c.pops++;
         int32_t ti = ~cur;
         uint32_t idx;
         do {
-            TriData q = load_tri(S, C, ti);
+            TriData q = load_tri<ONCHIP>(S, C, ti);
             idx = f2u(q.e.y);
             if (COUNT) c.tris++;
             float t, u, v;
@@ -165,7 +172,7 @@ PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d,
             }
             ti++;
         } while (!(idx & 0x80000000u));
-        cur = st.sp > 0 ? st.pop() : kRefNone;
+        cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
     }
     if (COUNT) { if (hit.tri >= 0) c.hits++; }
 }
@@ -178,7 +185,7 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 
 // BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
-template <bool COUNT, int N>
+template <bool COUNT, int N, bool ONCHIP = false>
 PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 thr = v3(1.0f);
@@ -186,13 +193,13 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
     int32_t cur = S.rootRef;
     if (COUNT) c.raysShadow++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+        while (cur >= 0) cur = descend<COUNT, N, ONCHIP>(S, C, cur, o, inv, st, c);
         if (cur == kRefNone) break;
         if (COUNT) c.pops++;
         int32_t ti = ~cur;
         uint32_t idx;
         do {
-            TriData q = load_tri(S, C, ti);
+            TriData q = load_tri<ONCHIP>(S, C, ti);
             idx = f2u(q.e.y);
             if (COUNT) c.tris++;
             float t, u, v;
@@ -213,7 +220,7 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
             }
             ti++;
         } while (!(idx & 0x80000000u));
-        cur = st.sp > 0 ? st.pop() : kRefNone;
+        cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
     }
     return thr;
 }
