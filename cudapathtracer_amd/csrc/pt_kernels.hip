@@ -111,7 +111,7 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 // Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
 // surface as an error code, never as a hung GPU.
 constexpr int kFreshBit = 1 << 30;
-constexpr unsigned long long kQueueTimeout = 3000000000ull;            // 30 s of the 100 MHz wall clock
+constexpr unsigned long long kQueueTimeout = 3000000000ull;            // 30 s of the 100 MHz wall clock without any progress
 #define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
@@ -120,7 +120,8 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
     if (lane == 0) {
         const unsigned pos = atomicAdd((unsigned*)&q[0], 1u);
         unsigned long long* slot = queue_slot(q, mask, pos);
-        const unsigned long long t0 = wall_clock64();
+        unsigned long long t0 = wall_clock64();
+        int seen = -1;
         for (unsigned spin = 0;; spin++) {
             const unsigned long long v = PT_QLOAD(slot);
             if ((unsigned)v == pos + 1u) {
@@ -130,8 +131,14 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
             }
             if (!mayWait) break;                                                // without time slices nothing is ever pushed
             if ((spin & 7) == 0) {
-                if (PT_QLOAD(&q[2]) >= nTiles || PT_QLOAD(&q[3]) != 0) break;   // frame finished, or somebody gave up
-                if (wall_clock64() - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 1); break; }
+                const int done = PT_QLOAD(&q[2]);
+                if (done >= nTiles || PT_QLOAD(&q[3]) != 0) break;              // frame finished, or somebody gave up
+                // the clock only runs while nothing moves: every running wave pushes or finishes within one time
+                // slice, so the end of a long frame (fewer tiles left than waves) is not a timeout
+                const int progress = done + PT_QLOAD(&q[1]);
+                const unsigned long long now = wall_clock64();
+                if (progress != seen) { seen = progress; t0 = now; }
+                else if (now - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 1); break; }
             }
             __builtin_amdgcn_s_sleep(64);
         }
