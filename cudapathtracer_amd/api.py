@@ -110,6 +110,7 @@ def lib():
     L.pt_get_counters.argtypes = [vp, vp]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
+    L.pt_scene_flags.argtypes = [vp]
     L.pt_debug_stamps.argtypes = [vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
@@ -349,6 +350,10 @@ class Scene:
         out = np.zeros(6, np.uint64)
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
         return dict(zip(("regen", "closest", "shade_pre", "shadow", "shade_post", "loop"), (int(v) for v in out)))
+
+    def flags(self):
+        f = lib().pt_scene_flags(self.h)
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4)}
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

@@ -565,6 +565,13 @@ static int queue_error(pt_scene* s) {
     return 0;
 }
 
+int pt_scene_flags(pt_scene* s) {
+    if (!s) return 0;
+    const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
+    const bool pers = s->persistent && !s->xcdBands;
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0);
+}
+
 float pt_last_kernel_ms(pt_scene* s) {
     if (!s) return -1.0f;
     if (s->evPending) {                                // waits for the last megakernel launch to finish

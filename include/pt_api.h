@@ -167,6 +167,9 @@ int pt_reset_counters(pt_scene* scene);
 /* Device time (ms) of the most recent megakernel launch on this scene, from HIP events recorded
  * on the launch stream around that kernel alone; waits for the launch to finish. */
 float pt_last_kernel_ms(pt_scene* scene);
+/* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
+ * bit 1 = persistent waves on the tile queue, bit 2 = time slices on. For labelling measurements. */
+int pt_scene_flags(pt_scene* scene);
 /* Diagnostic builds (-DPT_STAMPS) only: per-phase s_memtime sums of the megakernel since the last
  * pt_reset_counters: regen, closest traversal, shading before the shadow ray, shadow traversal,
  * shading after it, loop overhead. Zeros in a normal build. */
