@@ -353,7 +353,7 @@ class Scene:
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8)}
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

@@ -64,6 +64,7 @@ struct pt_scene {
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
+    bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
     bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
     int nTrisPacked = 0;
     int sliceIters = 512;        // PT_SLICE_ITERS: time slice of the tile queue once no fresh tile is left (0 = off)
@@ -286,6 +287,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
     if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
+    if (const char* e = getenv("PT_WAVES_HBM")) s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0;
     if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
@@ -391,9 +393,15 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (t.count == 0) return 0;
     // the reference keys the stream by the camera's image size (y*w+x with the launch's w, deviceCode.cu:59)
     if (int r = s->rng.ensure((size_t)t.count * 384 * sizeof(uint32_t))) return r;
+    // Which kernel (pt_kernels.hip): the LDS-resident instantiation, or — for a scene in HBM — the 6-waves-per-SIMD
+    // one with its shorter LDS stack (so the spill area is laid out for THAT stack length).
+    const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
+    const bool deferred = s->deferShadow && !s->armless;
+    const bool hbm = !onchip && !deferred && s->wavesHbmOk && integrator != 1;
+    const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
     int blocks = megakernel_blocks(t.count);
-    if (s->ds.stackSpill > 0)
-        if (int r = s->spill.ensure((size_t)blocks * 4 * s->ds.stackSpill * 64 * sizeof(int32_t))) return r;
+    if (spillEntries > 0)
+        if (int r = s->spill.ensure((size_t)blocks * 4 * spillEntries * 64 * sizeof(int32_t))) return r;
     // continueStreams: a later chunk of a progressive render keeps the per-pixel XORWOW states the
     // previous chunk stored (the reference reloads / stores them around every sample, deviceCode.cu:294, 541)
     if (!continueStreams) HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
@@ -405,7 +413,9 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
-    P.onchip = (s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0) ? 1 : 0;
+    P.S.stackSpill = spillEntries;
+    P.onchip = onchip ? 1 : 0;
+    P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
     P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
     P.lptPrio = s->lptPrio; P.sliceIters = s->sliceIters; P.schedMask = s->schedMask; P.sliceAlways = s->sliceAlways ? 1 : 0;
     if (s->persistent && !s->xcdBands) {
@@ -414,11 +424,11 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         if (int r = s->queue.ensure((size_t)(8 + 2 * cap) * sizeof(int))) return r;
         if (int r = s->left.ensure((size_t)t.count * 64 * sizeof(int))) return r;
         P.queue = (int*)s->queue.p; P.queueMask = cap - 1; P.left = (int*)s->left.p;
-        P.gridBlocks = s->numCU * 4;               // 16 waves per CU: 128 VGPRs (PT_MIN_WAVES = 4) and <= 40 KB LDS per workgroup
+        P.gridBlocks = s->numCU * P.wavesPerSimd;      // n waves per SIMD = n 4-wave workgroups per CU
     }
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
-    P.spill = s->ds.stackSpill > 0 ? (int32_t*)s->spill.p : nullptr;
+    P.spill = spillEntries > 0 ? (int32_t*)s->spill.p : nullptr;
     HIP_OK(hipEventRecord(s->ev0, stream));            // HIP events on the launch stream, around the megakernel only
     HIP_OK(launch_megakernel(integrator, count, !(s->deferShadow && !s->armless), P, stream));
     HIP_OK(hipEventRecord(s->ev1, stream));
@@ -569,7 +579,8 @@ int pt_scene_flags(pt_scene* s) {
     if (!s) return 0;
     const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
     const bool pers = s->persistent && !s->xcdBands;
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0);
+    const bool hbm = !onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk;
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

@@ -170,13 +170,10 @@ PT_DEV uint32_t state_load(const uint32_t* p, bool shared) { return shared ? PT_
 PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_QSTORE(p, v); else *p = v; }
 
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
-// scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP>
-__global__ void __launch_bounds__(256)
-#if PT_MIN_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
-#endif
-megakernel(KParams P) {
+// scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
+// stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN>
+PT_DEV void megakernel_body(const KParams& P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -212,12 +209,12 @@ megakernel(KParams P) {
     const bool inImage = (x < P.w) && (y < P.h);
 
     const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
-    Stack<kStackLds> st;
-    st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (kStackLds * 64) + lane;
+    Stack<STACKN> st;
+    st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (STACKN * 64) + lane;
     st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
     st.sp = 0;
     LdsMedium ms;
-    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + 4 * kStackLds * 256) + wave * (kMediumMax * 64) + lane;
+    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + 4 * STACKN * 256) + wave * (kMediumMax * 64) + lane;
 
     PathState ps;
     const bool shared = P.queue != nullptr && !COUNT && P.sliceIters > 0;       // tiles may change hands
@@ -240,7 +237,7 @@ megakernel(KParams P) {
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, kStackLds, ONCHIP>(S, SC, ro, wi, maxt, st, c); };
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP>(S, SC, ro, wi, maxt, st, c); };
 
 #ifdef PT_STAMPS
     unsigned long long stamp[2] = {0, 0};
@@ -310,8 +307,8 @@ megakernel(KParams P) {
         const bool hasShadow = DEFER && (ps.flags & kShadowPending) != 0;
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
-        if (DEFER) trace_pair<COUNT, kStackLds>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
-        else if (hasExt) trace_closest<COUNT, kStackLds, ONCHIP>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
+        if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
         PT_STAMP(1);
     }
 
@@ -362,6 +359,21 @@ megakernel(KParams P) {
     }
     }   // next tile
 }
+
+// Two register budgets (PMC counters): a scene that lives in LDS is VALU-bound and best at
+// 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
+// cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
+// included (5: +10 %, 7-8: no better). Both run the same body.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP>
+__global__ void __launch_bounds__(256)
+#if PT_MIN_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
+#endif
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds>(P); }
+
+template <int INTEG, bool COUNT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm>(P); }
 
 // -------------------------------------------------------------------------------------------
 // tile-major [local tile][64] <-> scan-line colors[y*w+x]
@@ -509,12 +521,15 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
         hipLaunchKernelGGL(queue_init_kernel, dim3((P.queueMask + 256) / 256), dim3(256), 0, stream, P.queue, P.queueMask, P.tileCount);
     }
     dim3 grid(nBlocks), block(256);
-    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris);
+    const bool hbm = P.wavesPerSimd == kWavesHbm;              // chosen by the host together with the spill layout
+    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : kStackLds);
 #define PT_LAUNCH_MK(I, C, D, O) hipLaunchKernelGGL((megakernel<I, C, D, O>), grid, block, lds, stream, P)
-#define PT_LAUNCH_MK2(I, D) do { if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, D, true); else PT_LAUNCH_MK(I, true, D, false); } \
-                                 else { if (P.onchip) PT_LAUNCH_MK(I, false, D, true); else PT_LAUNCH_MK(I, false, D, false); } } while (0)
-    if (integrator == 2) PT_LAUNCH_MK2(2, false);
-    else if (syncShadow) PT_LAUNCH_MK2(0, false);
+#define PT_LAUNCH_HBM(I, C) hipLaunchKernelGGL((megakernel_hbm<I, C>), grid, block, lds, stream, P)
+#define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
+                              else if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, true, false, false); } \
+                              else { if (P.onchip) PT_LAUNCH_MK(I, false, false, true); else PT_LAUNCH_MK(I, false, false, false); } } while (0)
+    if (integrator == 2) PT_LAUNCH_MK2(2);
+    else if (syncShadow) PT_LAUNCH_MK2(0);
     else { if (count) PT_LAUNCH_MK(0, true, true, false); else PT_LAUNCH_MK(0, false, true, false); }
     return hipGetLastError();
 }

@@ -16,6 +16,11 @@ namespace pt {
 #define PT_CACHE_BYTES 12288      // LDS bytes per workgroup for the scene cache (top PNodes / all PTris)
 #endif
 constexpr int kStackLds = PT_STACK_LDS;
+#ifndef PT_WAVES_HBM
+#define PT_WAVES_HBM 6             // waves per SIMD of the instantiation for scenes that do not fit the LDS cache (0 = use the 4-wave kernel)
+#endif
+constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
+constexpr int kStackLdsHbm = 8;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
 constexpr int kCacheBytes = PT_CACHE_BYTES;
 
@@ -25,6 +30,7 @@ struct KParams {
     int w, h, spp, maxDepth, useMIS;
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
+    int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)
     uint32_t* rng;                 // [tile][6][64]
@@ -105,8 +111,8 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
 // waves a probe_closest/shadow launch of n rays uses (spill sizing)
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
 inline int megakernel_blocks(int tileCount) { return (tileCount + 3) / 4; }
-inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris) {
-    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)kStackLds * 256 + 4 * (size_t)kMediumMax * 64;
+inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds) {
+    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)stackEntries * 256 + 4 * (size_t)kMediumMax * 64;
 }
 
 }  // namespace pt

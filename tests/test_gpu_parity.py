@@ -171,12 +171,16 @@ def test_render_matches_golden(api, gpu_ready, case):
     assert tot["rays_closest"] == int(g["counters"][..., 0].sum()) and tot["tri_tests"] == int(g["counters"][..., 4].sum())
 
 
-@pytest.mark.parametrize("sched", [("0", "31", "1"), ("4", "3", "2"), ("8", "7", "0"), ("512", "31", "2")])
+@pytest.mark.parametrize("sched", [("0", "31", "1", "1", "1"), ("4", "3", "2", "1", "1"), ("8", "7", "0", "0", "1"), ("512", "31", "2", "0", "1"),
+                                   ("4", "3", "2", "0", "0")])
 def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
-    """The timed (counters-off) kernel with its scheduling machinery driven hard: tiles are yielded after
-    4-8 bounce iterations, queued again and continued by whichever wave is free (production: 256), with and
-    without issue-priority steering. Scheduling must not reach the image: golden colours bit for bit."""
-    monkeypatch.setenv("PT_SLICE_ITERS", sched[0]); monkeypatch.setenv("PT_SCHED_MASK", sched[1]); monkeypatch.setenv("PT_LPT_PRIO", sched[2])
+    """The timed (counters-off) kernels with their scheduling machinery driven hard: tiles are yielded after
+    4-8 bounce iterations, queued again and continued by whichever wave is free (production: 512), with and
+    without issue-priority steering, through all three instantiations (LDS-resident; PT_ONCHIP=0: the
+    6-waves-per-SIMD kernel for scenes in HBM; PT_WAVES_HBM=0: the general 4-wave kernel). Scheduling and
+    register budget must not reach the image: golden colours bit for bit."""
+    for k, v in zip(("PT_SLICE_ITERS", "PT_SCHED_MASK", "PT_LPT_PRIO", "PT_ONCHIP", "PT_WAVES_HBM"), sched):
+        monkeypatch.setenv(k, v)
     for case in CASES:
         g = np.load(os.path.join(GOLDEN, case + ".npz"))
         hs = api.HostScene(golden_case_scene(g))
@@ -214,6 +218,10 @@ def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator):
     assert np.array_equal(cnt, ocnt)
     assert_bits_equal(col, ocol, "deep chain render")
     assert cnt[..., 5].sum() > 100
+    # counters off: the timed instantiation for scenes in HBM (8-entry LDS stack, so this tree spills 42 deep)
+    col2, _ = gs.render(cam, 24, 16, 4, 5, integrator=integrator)
+    assert_bits_equal(col2, ocol, "deep chain render, timed kernel")
+    assert gs.flags()["hbm_kernel"] and not gs.flags()["onchip"]
 
 
 @pytest.mark.parametrize("case", CASES)
