@@ -65,6 +65,7 @@ struct pt_scene {
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
+    bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
     bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
     int nTrisPacked = 0;
     int sliceIters = 512;        // PT_SLICE_ITERS: time slice of the tile queue once no fresh tile is left (0 = off)
@@ -287,7 +288,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
     if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
-    if (const char* e = getenv("PT_WAVES_HBM")) s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0;
+    if (const char* e = getenv("PT_WAVES_HBM")) { s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && e[0] == '2'; }
     if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
@@ -397,7 +398,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     // one with its shorter LDS stack (so the spill area is laid out for THAT stack length).
     const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
     const bool deferred = s->deferShadow && !s->armless;
-    const bool hbm = !onchip && !deferred && s->wavesHbmOk && integrator != 1;
+    // ... and only with enough tiles to fill its 6 waves per SIMD: with fewer (a 1/8 shard of a 1080p frame is 4050
+    // tiles for 6144 slots) the extra slots stay empty and the 4-wave kernel's faster waves win (measured: 1/8 shard
+    // 176 vs 185 ms, 1/4 shard equal, 1/2 shard 602 vs 518 ms on the 263 k-triangle scene).
+    const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * kWavesHbm * 5);
     const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
     int blocks = megakernel_blocks(t.count);
     if (spillEntries > 0)

@@ -171,13 +171,14 @@ def test_render_matches_golden(api, gpu_ready, case):
     assert tot["rays_closest"] == int(g["counters"][..., 0].sum()) and tot["tri_tests"] == int(g["counters"][..., 4].sum())
 
 
-@pytest.mark.parametrize("sched", [("0", "31", "1", "1", "1"), ("4", "3", "2", "1", "1"), ("8", "7", "0", "0", "1"), ("512", "31", "2", "0", "1"),
+@pytest.mark.parametrize("sched", [("0", "31", "1", "1", "1"), ("4", "3", "2", "1", "1"), ("8", "7", "0", "0", "2"), ("512", "31", "2", "0", "2"),
                                    ("4", "3", "2", "0", "0")])
 def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
     """The timed (counters-off) kernels with their scheduling machinery driven hard: tiles are yielded after
     4-8 bounce iterations, queued again and continued by whichever wave is free (production: 512), with and
     without issue-priority steering, through all three instantiations (LDS-resident; PT_ONCHIP=0: the
-    6-waves-per-SIMD kernel for scenes in HBM; PT_WAVES_HBM=0: the general 4-wave kernel). Scheduling and
+    6-waves-per-SIMD kernel for scenes in HBM, forced by PT_WAVES_HBM=2 although these frames have few tiles;
+    PT_WAVES_HBM=0: the general 4-wave kernel). Scheduling and
     register budget must not reach the image: golden colours bit for bit."""
     for k, v in zip(("PT_SLICE_ITERS", "PT_SCHED_MASK", "PT_LPT_PRIO", "PT_ONCHIP", "PT_WAVES_HBM"), sched):
         monkeypatch.setenv(k, v)
@@ -208,8 +209,9 @@ def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integr
 
 
 @pytest.mark.parametrize("integrator", [0, 2])
-def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator):
+def test_render_hand_built_deep_tree(api, oracle, gpu_ready, monkeypatch, integrator):
     """Array-level boundary + a tree deeper than the LDS stack, through the full render loop."""
+    monkeypatch.setenv("PT_WAVES_HBM", "2")              # the 6-wave kernel also for this 6-tile frame
     arr = _chain_arrays(api)
     gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
     cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
