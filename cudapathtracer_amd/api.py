@@ -349,7 +349,7 @@ class Scene:
     def debug_stamps(self):
         out = np.zeros(6, np.uint64)
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
-        return dict(zip(("regen", "closest", "shade_pre", "shadow", "shade_post", "loop"), (int(v) for v in out)))
+        return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end"), (int(v) for v in out)))
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)

@@ -240,7 +240,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP>(S, SC, ro, wi, maxt, st, c); };
 
 #ifdef PT_STAMPS
-    unsigned long long stamp[2] = {0, 0};
+    unsigned long long stamp[3] = {0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long wall0 = wall_clock64();     // device-wide 100 MHz clock: slot occupancy (tools/stamps.py)
 #endif
@@ -298,6 +298,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
             if (done) path_finish(ps, acc, DEFER);
         }
+        PT_STAMP(2);                                   // slot 2: scheduling check + bounce logic (shading, NEE shadow ray)
         while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
             samplesLeft--;
             path_begin<COUNT>(P.cam, ps, ms, x, y, c);
@@ -318,11 +319,11 @@ PT_DEV void megakernel_body(const KParams& P) {
     }
 #ifdef PT_STAMPS
     if (P.totals && lane == 0) {
-        for (int k = 0; k < 2; k++) atomicAdd(&P.totals[8 + k], stamp[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(&P.totals[8 + k], stamp[k]);   // regeneration, closest-hit traversal, bounce logic
         const unsigned long long wall1 = wall_clock64();
-        atomicAdd(&P.totals[10], wall1 - wall0);             // sum of wave lifetimes
-        atomicMax(&P.totals[11], ~wall0);                     // ~(earliest start)
-        atomicMax(&P.totals[12], wall1);                      // latest end
+        atomicAdd(&P.totals[11], wall1 - wall0);             // sum of wave lifetimes
+        atomicMax(&P.totals[12], ~wall0);                     // ~(earliest start)
+        atomicMax(&P.totals[13], wall1);                      // latest end
     }
 #endif
     if (inImage) {

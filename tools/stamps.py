@@ -15,7 +15,7 @@ sc.reset_counters()
 sc.render_tiles_device(hs.camera(), 1920, 1080, spp, 8, tiles.data_ptr(), count_work=True)
 torch.cuda.synchronize()
 st = sc.debug_stamps()
-life, nstart, end = st.pop("shade_pre"), st.pop("shadow"), st.pop("shade_post"); st.pop("loop")
+life, nstart, end = st.pop("wave_lifetimes"), st.pop("not_earliest_start"), st.pop("latest_end")
 span = end - ((~nstart) & (2**64 - 1))
 if span > 0:
     slots = 256 * 16
