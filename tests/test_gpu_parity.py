@@ -347,6 +347,35 @@ def test_device_tile_path_and_untile(api, gpu_ready):
     assert_bits_equal(frame.cpu().numpy(), g["colors"], "device tile path")
 
 
+def test_baseline_config0_cornell256(api, oracle, gpu_ready, scene_dir):
+    """BASELINE.json configs[0] — Cornell box 256x256, 16 spp, 4 bounces, the reference's CPU-runnable case — on the
+    GPU against the host loop of the oracle: radiance and work counters bit for bit, both integrators' launchers."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.cornell(os.path.join(scene_dir, "c1"), 256, 256, 16, 4, name="c1")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    col, cnt = gs.render(hs.camera(), 256, 256, 16, 4, counters=True)
+    ocol, ocnt, _ = osc.render(counters=True, threads=8)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col, ocol, "C1 Cornell 256x256x16spp")
+    timed, _ = gs.render(hs.camera(), 256, 256, 16, 4)                       # the counters-off instantiation
+    assert_bits_equal(timed, ocol, "C1, timed kernel")
+    gs.set_variant("wavefront")
+    wf, _ = gs.render(hs.camera(), 256, 256, 16, 4)
+    assert_bits_equal(wf, ocol, "C1, wavefront variant")
+
+
+def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
+    """Camera::NotPinhole (objects.cuh:237-264): aperture 0.08, focal distance 2.2, rotated — through the full loop."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.cornell(os.path.join(scene_dir, "lens"), 48, 32, 6, 5, name="lens")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    cam = api.Camera.NotPinhole((0.15, -0.1, 1.2), 48, 32, (3.0, -8.0, 2.0), 55.0, 0.08, 2.2)
+    col, cnt = gs.render(cam, 48, 32, 6, 5, counters=True)
+    ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=48, height=32, spp=6, max_depth=5, counters=True)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col, ocol, "thin-lens render")
+
+
 def test_full_size_properties(api, gpu_ready, scene_dir):
     """BASELINE C2 geometry at full 1920x1080 (2 spp): properties that need no oracle run."""
     from cudapathtracer_amd import scenes

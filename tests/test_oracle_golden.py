@@ -56,3 +56,20 @@ def test_finalise(oracle):
     c[0, 0] = [4, 8, 12, 0]; c[0, 1] = [np.nan, 1, 1, 0]; c[1, 0] = [np.inf, 1, 1, 0]
     f = oracle.finalise(c, 4).reshape(2, 2, 4)
     assert np.array_equal(f[0, 0, :3], [1, 2, 3]) and np.array_equal(f[0, 1, :3], [1, 0, 1]) and np.array_equal(f[1, 0, :3], [0, 1, 0])
+
+
+def test_baseline_config0_host_loop(oracle, scene_dir):
+    """BASELINE.json configs[0]: Cornell 256x256, 16 spp, 4 bounces through the single-thread host loop.
+    Pinned by digest (a regression pin of the restatement, not a reference pin: oracle/README.md) and checked
+    against the 8-thread run — the per-pixel streams make the image independent of the thread count."""
+    import hashlib
+    from cudapathtracer_amd import scenes
+    s = scenes.cornell(os.path.join(scene_dir, "c1"), 256, 256, 16, 4, name="c1")
+    assert s["sha256"] == "a8a5cd2e4b5eab82d1ef22e22ac7589bf78280791e05652bea0d4195c63bfc63"   # the generated scene itself
+    sc = oracle.OracleScene(s["config"])
+    a, ca, _ = sc.render(counters=True, threads=1)
+    b, cb, _ = sc.render(counters=True, threads=8)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(ca, cb)
+    assert int(ca[..., 0].sum()) == 4720774                                   # closest-hit rays of the frame
+    assert hashlib.sha256(a.tobytes()).hexdigest() == "615b8397923e2b526aa64713ad524803550a64fb0f741e40b09348a2f8e73927"
+    assert hashlib.sha256(ca.tobytes()).hexdigest() == "de43006ee22d1cbab2f3e305d5d450501b05f6458da2a0757b45355193e0e23c"
