@@ -364,6 +364,25 @@ def test_baseline_config0_cornell256(api, oracle, gpu_ready, scene_dir):
     assert_bits_equal(wf, ocol, "C1, wavefront variant")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 3, 4), (7, 9, 2, 3), (33, 9, 1, 1), (16, 8, 5, 0), (8, 8, 0, 4), (130, 3, 2, 2)])
+def test_edge_frames(api, oracle, gpu_ready, scene_dir, shape):
+    """Frames smaller than a tile, ragged edges, one sample, zero samples, depth 0 and 1 — timed and counted kernels."""
+    from cudapathtracer_amd import scenes
+    w, h, spp, depth = shape
+    cfg = scenes.cornell(os.path.join(scene_dir, "edge"), 16, 16, 2, 4, name="edge")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    cam = api.Camera.Pinhole((0, 0, 1), w, h)
+    ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=w, height=h, spp=spp, max_depth=depth, counters=True)
+    for integ in (0, 2):
+        if integ == 2:
+            ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=w, height=h, spp=spp, max_depth=depth, integrator=2, counters=True)
+        col, cnt = gs.render(cam, w, h, spp, depth, integrator=integ, counters=True)
+        assert np.array_equal(cnt, ocnt), (shape, integ)
+        assert_bits_equal(col, ocol, "edge frame %s integrator %d" % (shape, integ))
+        timed, _ = gs.render(cam, w, h, spp, depth, integrator=integ)
+        assert_bits_equal(timed, ocol, "edge frame %s integrator %d, timed kernel" % (shape, integ))
+
+
 def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
     """Camera::NotPinhole (objects.cuh:237-264): aperture 0.08, focal distance 2.2, rotated — through the full loop."""
     from cudapathtracer_amd import scenes
