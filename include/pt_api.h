@@ -124,7 +124,9 @@ int pt_render(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, i
               int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles, float* out_rgba_sum);
 
 /* Device-resident forms, asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * d_tile_rgba: count*64 float4, tile-major ([local tile][ly*8+lx]); += semantics. */
+ * d_tile_rgba: count*64 float4, tile-major ([local tile][ly*8+lx]); += semantics.
+ * A pt_scene owns its work buffers (per-pixel RNG states, tile queue, traversal spill area): launches on ONE
+ * scene must be ordered (same stream, or synchronised); different scenes are independent. */
 int pt_render_tiles_device(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
                            int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles,
                            void* d_tile_rgba, int count_work, void* stream);
