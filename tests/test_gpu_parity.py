@@ -383,6 +383,32 @@ def test_edge_frames(api, oracle, gpu_ready, scene_dir, shape):
         assert_bits_equal(timed, ocol, "edge frame %s integrator %d, timed kernel" % (shape, integ))
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_scenes(api, oracle, gpu_ready, scene_dir, seed):
+    """Seeded random scenes (scenes.fuzz): random materials from the whole table on walls and objects, nested and
+    interpenetrating dielectrics, leaves in front of lights, several emitters, random leaf size. Both integrators,
+    counted and timed kernels, wavefront variant (where every material has a dispatch arm): bit for bit."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.fuzz(os.path.join(scene_dir, "fuzz%d" % seed), seed)["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    i = hs.info
+    for integ in (0, 2):
+        ocol, ocnt, _ = osc.render(integrator=integ, counters=True, threads=8)
+        col, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ, counters=True)
+        assert np.array_equal(cnt, ocnt), (seed, integ)
+        assert_bits_equal(col, ocol, "fuzz %d integrator %d" % (seed, integ))
+        timed, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ)
+        assert_bits_equal(timed, ocol, "fuzz %d integrator %d, timed kernel" % (seed, integ))
+    try:
+        gs.set_variant("wavefront")
+        wf, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=0)
+    except api.PtError as e:
+        assert "dispatch arm" in str(e)                     # armless material types: the variant refuses, by design
+    else:
+        ocol, _, _ = osc.render(integrator=0, threads=8)
+        assert_bits_equal(wf, ocol, "fuzz %d, wavefront" % seed)
+
+
 def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
     """Camera::NotPinhole (objects.cuh:237-264): aperture 0.08, focal distance 2.2, rotated — through the full loop."""
     from cudapathtracer_amd import scenes

@@ -103,3 +103,12 @@ def test_parser_and_obj_quirks(api, oracle, tmp_path):
 def test_missing_files(api):
     with pytest.raises(api.PtError):
         api.HostScene("/nonexistent/x.rendertron")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_scenes_load_identically(api, oracle, scene_dir, seed):
+    """Random scenes (every row of the material table, fans with per-vertex normals / uvs, several emitters,
+    leaf sizes 1-5): the kept loader and the restatement's loader, written independently, agree byte for byte."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.fuzz(os.path.join(scene_dir, "lfuzz%d" % seed), seed)["config"]
+    _same_arrays(api.HostScene(cfg), oracle.OracleScene(cfg))
