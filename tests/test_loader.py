@@ -111,4 +111,4 @@ def test_fuzz_scenes_load_identically(api, oracle, scene_dir, seed):
     leaf sizes 1-5): the kept loader and the restatement's loader, written independently, agree byte for byte."""
     from cudapathtracer_amd import scenes
     cfg = scenes.fuzz(os.path.join(scene_dir, "lfuzz%d" % seed), seed)["config"]
-    _same_arrays(api.HostScene(cfg), oracle.OracleScene(cfg))
+    _same(api, oracle, cfg)
