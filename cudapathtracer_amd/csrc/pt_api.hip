@@ -65,6 +65,7 @@ struct pt_scene {
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
+    int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
     bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
     int nTrisPacked = 0;
@@ -418,6 +419,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
+    s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
     P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
@@ -583,7 +585,8 @@ int pt_scene_flags(pt_scene* s) {
     if (!s) return 0;
     const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
     const bool pers = s->persistent && !s->xcdBands;
-    const bool hbm = !onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk;
+    // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
+    const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
     return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0);
 }
 

@@ -170,7 +170,7 @@ int pt_reset_counters(pt_scene* scene);
  * on the launch stream around that kernel alone; waits for the launch to finish. */
 float pt_last_kernel_ms(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
- * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM. For labelling measurements. */
+ * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM (as used by the last launch; it needs enough tiles). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Diagnostic builds (-DPT_STAMPS) only: per-phase s_memtime sums of the megakernel since the last
  * pt_reset_counters: regen, closest traversal, shading before the shadow ray, shadow traversal,
