@@ -421,6 +421,30 @@ def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
     assert_bits_equal(col, ocol, "thin-lens render")
 
 
+def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir, monkeypatch):
+    """1920x1080 Cornell, 48 spp: the frame from one-tile-per-wave workgroups (no queue at all) against the
+    persistent kernel forced to yield every 32 iterations — some 300 000 hand-overs of tile state between waves
+    on all eight XCDs — and against the production setting. Bit for bit, twice (no run-to-run variation)."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.cornell(os.path.join(scene_dir, "c2s"), 1920, 1080, 48, 8, name="c2s")["config"]
+    hs = api.HostScene(cfg)
+    frames = []
+    for env in ({"PT_PERSISTENT": "0"}, {"PT_SLICE_ITERS": "32", "PT_SCHED_MASK": "7"}, {}, {"PT_SLICE_ITERS": "32", "PT_SCHED_MASK": "7", "PT_ONCHIP": "0", "PT_WAVES_HBM": "2"}):
+        for k in ("PT_PERSISTENT", "PT_SLICE_ITERS", "PT_SCHED_MASK", "PT_ONCHIP", "PT_WAVES_HBM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc = api.Scene(hs)
+        a, _ = sc.render(hs.camera(), 1920, 1080, 48, 8)
+        b, _ = sc.render(hs.camera(), 1920, 1080, 48, 8)
+        assert sc.last_kernel_ms() > 0.0
+        assert_bits_equal(a, b, "run-to-run %s" % env)
+        frames.append(a)
+        sc.close()
+    for f in frames[1:]:
+        assert_bits_equal(f, frames[0], "scheduling reached the image")
+
+
 def test_full_size_properties(api, gpu_ready, scene_dir):
     """BASELINE C2 geometry at full 1920x1080 (2 spp): properties that need no oracle run."""
     from cudapathtracer_amd import scenes
