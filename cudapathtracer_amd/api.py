@@ -98,6 +98,8 @@ def lib():
     L.pt_last_error.restype = C.c_char_p
     L.pt_device_count.restype = i32
     L.pt_scene_create.restype = vp; L.pt_scene_create.argtypes = [C.POINTER(SceneDesc)]
+    L.pt_scene_create_from_mesh.restype = vp; L.pt_scene_create_from_mesh.argtypes = [C.POINTER(SceneDesc), i32, vp]
+    L.pt_debug_packed.argtypes = [vp, i32, vp, C.c_size_t]
     L.pt_scene_destroy.argtypes = [vp]
     L.pt_render.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, C.POINTER(TileRange), vp]
     L.pt_render_counted.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, C.POINTER(TileRange), vp, vp]
@@ -267,6 +269,31 @@ class Scene:
         self.h = lib().pt_scene_create(C.byref(d))
         if not self.h:
             raise PtError("pt_scene_create failed: " + lib().pt_last_error().decode(errors="replace"))
+
+    @staticmethod
+    def from_mesh(host: "HostScene", max_leaf_size=None):
+        """pt_scene_create_from_mesh: BVH build (reference tree) and re-layout on the device from the host scene's
+        geometry; its host-built tree is not used. Returns the scene; `.build_stats` has the builder's numbers."""
+        st = np.zeros(1, BUILD_STATS)
+        leaf = host.info["leaf_size"] if max_leaf_size is None else int(max_leaf_size)
+        h = lib().pt_scene_create_from_mesh(C.byref(host.desc), leaf, _p(st))
+        if not h:
+            raise PtError("pt_scene_create_from_mesh failed: " + lib().pt_last_error().decode(errors="replace"))
+        sc = Scene.__new__(Scene)
+        sc.h = h; sc._keep = host
+        sc.build_stats = {f: st[0][f].item() for f in BUILD_STATS.names}
+        return sc
+
+    def packed(self, what):
+        """Test hook (pt_debug_packed): the traversal records as uint8 [count, record size]; what = nodes / tris / attrs."""
+        code, rec = {"nodes": (0, 64), "tris": (1, 48), "attrs": (2, 80)}[what]
+        n = lib().pt_debug_packed(self.h, code, None, 0)
+        if n < 0:
+            raise PtError("pt_debug_packed failed")
+        buf = np.zeros((max(n, 0), rec), np.uint8)
+        if n:
+            lib().pt_debug_packed(self.h, code, _p(buf), buf.nbytes)
+        return buf
 
     @staticmethod
     def from_arrays(arrays):

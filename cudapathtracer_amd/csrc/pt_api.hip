@@ -112,16 +112,28 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
 }
 
 // Re-pack the reference's data model for gfx950.
-static int repack(pt_scene* s, const pt_scene_desc* d) {
-    const int nT = d->n_triangles, nN = d->n_nodes;
-    if (nT <= 0 || nN <= 0 || !d->triangles || !d->bvh || !d->bvh_indices || !d->positions || !d->materials)
+extern "C" int pt_bvh_build_pack_(const pt_scene_desc* d, const int* mat_types, int max_leaf_size, void* d_nodes, void* d_tris, void* d_attrs,
+                                  int* out5, pt_bvh_build_stats* stats);
+
+// deviceLeaf < 0: the caller's BVH, packed on the host. deviceLeaf >= 0 (pt_scene_create_from_mesh): the tree is built AND
+// packed on the device (pt_bvh_build.hip) with that leaf size; d->bvh / d->bvh_indices are not read.
+static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_bvh_build_stats* buildStats = nullptr) {
+    const bool onDevice = deviceLeaf >= 0;
+    const int nT = d->n_triangles, nN = onDevice ? 1 : d->n_nodes;
+    if (nT <= 0 || nN <= 0 || !d->triangles || (!onDevice && (!d->bvh || !d->bvh_indices)) || !d->positions || !d->materials)
         return fail(-1, "pt_scene_create: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
     if (d->n_materials <= 0 || d->n_materials > 256) return fail(-1, "pt_scene_create: %d materials (1..256 supported)", d->n_materials);
 
+    int nInternal = 0, stackNeed = 0, rootRef = 0;
+    std::vector<PNode> nodes; std::vector<PTri> tris; std::vector<PAttr> attrs;
+    auto pos = [&](int i, const char* what, int tri, bool& ok) -> pt_float4 {
+        if (i < 0 || i >= d->n_positions) { ok = false; fail(-1, "pt_scene_create: triangle %d %s index %d out of range", tri, what, i); return pt_float4{0, 0, 0, 0}; }
+        return d->positions[i];
+    };
+    if (!onDevice) {
     // --- internal nodes renumbered BREADTH-FIRST from the root, so PNodes [0, K) are the top of the
     //     tree (the part every ray visits) and can be staged in LDS as one contiguous block ---
     std::vector<int> internalId(nN, -1);
-    int nInternal = 0;
     for (int i = 0; i < nN; i++) {
         const pt_bvh_node& n = d->bvh[i];
         if (n.primCount > 0) {
@@ -144,7 +156,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         }
     }
     auto childRef = [&](int c) -> int32_t { return d->bvh[c].primCount > 0 ? ~d->bvh[c].first : internalId[c]; };
-    std::vector<PNode> nodes(std::max(nInternal, 1));
+    nodes.assign(std::max(nInternal, 1), PNode{});
     std::vector<uint8_t> leafEnd(nT, 0);
     for (int i = 0; i < nN; i++) {
         const pt_bvh_node& n = d->bvh[i];
@@ -161,7 +173,6 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     }
     // stack need = the largest number of internal nodes on a root-to-leaf path (each can leave one
     // far child pending); also rejects cycles.
-    int stackNeed = 0;
     {
         std::vector<std::pair<int, int>> st; st.push_back({0, 1});
         size_t visited = 0;
@@ -177,11 +188,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     if (stackNeed > 128) return fail(-1, "pt_scene_create: BVH depth %d exceeds the reference's nodeStack[128] (integratorUtilities.cuh:89)", stackNeed);
 
     // --- triangles in leaf order ---
-    auto pos = [&](int i, const char* what, int tri, bool& ok) -> pt_float4 {
-        if (i < 0 || i >= d->n_positions) { ok = false; fail(-1, "pt_scene_create: triangle %d %s index %d out of range", tri, what, i); return pt_float4{0, 0, 0, 0}; }
-        return d->positions[i];
-    };
-    std::vector<PTri> tris(nT);
+    tris.resize(nT);
     for (int i = 0; i < nT; i++) {
         int idx = d->bvh_indices[i];
         if (idx < 0 || idx >= nT) return fail(-1, "pt_scene_create: BVHindices[%d] = %d out of range", i, idx);
@@ -203,7 +210,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         }
     }
     // --- hit attributes by original index ---
-    std::vector<PAttr> attrs(nT);
+    attrs.resize(nT);
     for (int i = 0; i < nT; i++) {
         const pt_triangle& t = d->triangles[i];
         PAttr& a = attrs[i];
@@ -218,6 +225,8 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         a.emission[0] = t.emission.x; a.emission[1] = t.emission.y; a.emission[2] = t.emission.z;
         a.material = t.materialID;
         a.lightInd = (t.lightInd >= 0 && t.lightInd < d->n_lights) ? t.lightInd : -51;
+    }
+    rootRef = childRef(0);
     }
     // --- lights ---
     std::vector<PLight> lights(std::max(d->n_lights, 1));
@@ -253,9 +262,22 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
         p.absorption[0] = m.absorption.x; p.absorption[1] = m.absorption.y; p.absorption[2] = m.absorption.z;
     }
 
-    if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
-    if (int r = upload(s->tris, tris.data(), tris.size() * sizeof(PTri))) return r;
-    if (int r = upload(s->attrs, attrs.data(), attrs.size() * sizeof(PAttr))) return r;
+    if (!onDevice) {
+        if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
+        if (int r = upload(s->tris, tris.data(), tris.size() * sizeof(PTri))) return r;
+        if (int r = upload(s->attrs, attrs.data(), attrs.size() * sizeof(PAttr))) return r;
+    } else {
+        if (int r = s->nodes.ensure((size_t)nT * sizeof(PNode))) return r;
+        if (int r = s->tris.ensure((size_t)nT * sizeof(PTri))) return r;
+        if (int r = s->attrs.ensure((size_t)nT * sizeof(PAttr))) return r;
+        std::vector<int> types(d->n_materials);
+        for (int i = 0; i < d->n_materials; i++) types[i] = d->materials[i].type;
+        int out5[5] = {0, 0, 0, 0, 0};
+        if (int r = pt_bvh_build_pack_(d, types.data(), deviceLeaf, s->nodes.p, s->tris.p, s->attrs.p, out5, buildStats)) return r;
+        nInternal = out5[0]; stackNeed = out5[1]; rootRef = out5[2];
+        if (out5[3]) s->armless = true;
+        if (stackNeed > 128) return fail(-1, "pt_scene_create_from_mesh: BVH depth %d exceeds the reference's nodeStack[128] (integratorUtilities.cuh:89)", stackNeed);
+    }
     if (int r = upload(s->lights, lights.data(), lights.size() * sizeof(PLight))) return r;
     if (int r = upload(s->mats, mats.data(), mats.size() * sizeof(PMat))) return r;
     if (int r = upload(s->textures, d->textures, (size_t)std::max(d->n_texels, 0) * sizeof(float4))) return r;
@@ -268,7 +290,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     s->stackNeed = stackNeed;
     s->ds.nodes = (const PNode*)s->nodes.p; s->ds.tris = (const PTri*)s->tris.p; s->ds.attrs = (const PAttr*)s->attrs.p;
     s->ds.lights = (const PLight*)s->lights.p; s->ds.mats = (const PMat*)s->mats.p; s->ds.textures = (const float4*)s->textures.p;
-    s->ds.rootRef = childRef(0);
+    s->ds.rootRef = rootRef;
     s->ds.nLights = d->n_lights; s->ds.nTris = nT;
     s->ds.stackSpill = std::max(0, stackNeed - kStackLds);
     // scene cache: everything if it fits the LDS budget, else only the top of the (breadth-first) tree
@@ -278,7 +300,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d) {
     return 0;
 }
 
-pt_scene* pt_scene_create(const pt_scene_desc* desc) {
+static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_build_stats* stats) {
     if (!desc) { fail(-1, "pt_scene_create: null desc"); return nullptr; }
     pt_scene* s = new pt_scene();
     if (hipError_t e = hipGetDevice(&s->device); e != hipSuccess) {
@@ -286,7 +308,7 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
         delete s;
         return nullptr;
     }
-    if (repack(s, desc) != 0) { pt_scene_destroy(s); return nullptr; }
+    if (repack(s, desc, deviceLeaf, stats) != 0) { pt_scene_destroy(s); return nullptr; }
     if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
     if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
     if (const char* e = getenv("PT_WAVES_HBM")) { s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && e[0] == '2'; }
@@ -302,6 +324,26 @@ pt_scene* pt_scene_create(const pt_scene_desc* desc) {
     }
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { fail(-2, "hipEventCreate failed"); pt_scene_destroy(s); return nullptr; }
     return s;
+}
+
+pt_scene* pt_scene_create(const pt_scene_desc* desc) { return create_scene(desc, -1, nullptr); }
+
+pt_scene* pt_scene_create_from_mesh(const pt_scene_desc* desc, int max_leaf_size, pt_bvh_build_stats* stats) {
+    if (max_leaf_size < 0) { fail(-1, "pt_scene_create_from_mesh: negative leaf size"); return nullptr; }
+    return create_scene(desc, max_leaf_size, stats);
+}
+
+// what: 0 PNodes (64 B each), 1 PTris (48 B), 2 PAttrs (80 B). Returns the record count (or < 0); copies
+// min(count * size, capacity) bytes. For tests: the device re-layout must equal the host one.
+int pt_debug_packed(pt_scene* s, int what, void* dst, size_t capacity) {
+    if (!s) return fail(-1, "null scene");
+    const void* src = what == 0 ? s->nodes.p : what == 1 ? s->tris.p : what == 2 ? s->attrs.p : nullptr;
+    const size_t rec = what == 0 ? sizeof(PNode) : what == 1 ? sizeof(PTri) : sizeof(PAttr);
+    const int count = what == 0 ? s->nInternal : s->nTrisPacked;
+    if (!src) return fail(-1, "pt_debug_packed: unknown array %d", what);
+    const size_t bytes = std::min((size_t)count * rec, capacity);
+    if (dst && bytes) HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return count;
 }
 
 // ---- helpers ----------------------------------------------------------------------------------

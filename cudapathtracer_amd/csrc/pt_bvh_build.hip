@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#include "pt_device.h"
 
 extern "C" int pt_fail_(int code, const char* msg);
 
@@ -678,25 +679,93 @@ void carve(Carver& c, Arrays& A, int n, int nPos, int maxBins) {
     A.ctl = c.take<Ctl>(1);
 }
 
+// ---- re-layout on the device: the packed records the kernels traverse, straight from the
+// builder's arrays. Same contents as pt_api.hip's host re-pack; PNodes are numbered in the builder's
+// breadth-first order (children of one level in allocation order, which is any valid breadth-first order).
+struct PackIn { const pt_float4* normals; int nNormals; const pt_float2* uvs; int nUvs; const int* matType; int nMats; int nLights; };
+__global__ void k_pack_flags(Arrays A, int total, unsigned char* F) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < total) F[o] = A.out[o].count > 0 ? 0 : 1;
+}
+__global__ void k_pack_nodes(Arrays A, int total, const int* iid, pt::PNode* nodes, unsigned char* leafEnd) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const OutNode& n = A.out[o];
+    if (n.count > 0) { leafEnd[n.first + n.count - 1] = 1; return; }
+    const OutNode &L = A.out[n.left], &R = A.out[n.right];
+    pt::PNode p;
+    for (int k = 0; k < 3; k++) { p.lmin[k] = L.lo[k]; p.lmax[k] = L.hi[k]; p.rmin[k] = R.lo[k]; p.rmax[k] = R.hi[k]; }
+    p.left = L.count > 0 ? ~L.first : iid[n.left];
+    p.right = R.count > 0 ? ~R.first : iid[n.right];
+    p.pad0 = p.pad1 = 0;
+    nodes[iid[o]] = p;
+}
+__global__ void k_pack_tris(Arrays A, const int* idx, PackIn in, const unsigned char* leafEnd, pt::PTri* tris, int* flagsOut) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const int id = idx[i];
+    const pt_triangle t = A.mesh[id];
+    const pt_float4 a = A.pos[t.aInd], b = A.pos[t.bInd], c = A.pos[t.cInd];      // indices checked by k_prims
+    pt::PTri p;
+    p.v0[0] = a.x; p.v0[1] = a.y; p.v0[2] = a.z;
+    p.e1[0] = b.x - a.x; p.e1[1] = b.y - a.y; p.e1[2] = b.z - a.z;      // trib - tria, integratorUtilities.cuh:13
+    p.e2[0] = c.x - a.x; p.e2[1] = c.y - a.y; p.e2[2] = c.z - a.z;      // tric - tria, :14
+    p.idx = (uint32_t)id | (leafEnd[i] ? 0x80000000u : 0u);
+    int mat = t.materialID;
+    if (mat < 0 || mat >= in.nMats) { atomicOr(flagsOut, 1); mat = 0; }
+    p.material = mat;
+    const int ty = in.matType[mat];
+    p.flags = ty == PT_MAT_LEAF ? 1u : 0u;
+    if (!(ty == PT_MAT_DIFFUSE || ty == PT_MAT_METAL || ty == PT_MAT_SMOOTHDIELECTRIC || ty == PT_MAT_LEAF || ty == PT_MAT_DELTAMIRROR)) atomicOr(flagsOut, 0x100);
+    tris[i] = p;
+}
+__global__ void k_pack_attrs(Arrays A, PackIn in, pt::PAttr* attrs, int* flagsOut) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const pt_triangle t = A.mesh[i];
+    pt::PAttr a;
+    const int ni[3] = {t.naInd, t.nbInd, t.ncInd}, ui[3] = {t.uvaInd, t.uvbInd, t.uvcInd};
+    float* nd[3] = {a.n0, a.n1, a.n2}; float* ud[3] = {a.uv0, a.uv1, a.uv2};
+    for (int k = 0; k < 3; k++) {
+        int nk = ni[k], uk = ui[k];
+        if (nk < 0 || nk >= in.nNormals) { atomicOr(flagsOut, 2); nk = 0; }
+        if (uk < 0 || uk >= in.nUvs) { atomicOr(flagsOut, 4); uk = 0; }
+        const pt_float4 nn = in.nNormals > 0 ? in.normals[nk] : pt_float4{0, 0, 0, 0};
+        const pt_float2 uu = in.nUvs > 0 ? in.uvs[uk] : pt_float2{0, 0};
+        nd[k][0] = nn.x; nd[k][1] = nn.y; nd[k][2] = nn.z;
+        ud[k][0] = uu.x; ud[k][1] = uu.y;
+    }
+    a.emission[0] = t.emission.x; a.emission[1] = t.emission.y; a.emission[2] = t.emission.z;
+    a.material = t.materialID;
+    a.lightInd = (t.lightInd >= 0 && t.lightInd < in.nLights) ? t.lightInd : -51;
+    attrs[i] = a;
+}
+
+struct Built {                        // what build_core leaves on the device (pool still allocated)
+    void* pool = nullptr;
+    Arrays A{};
+    int* idx = nullptr;               // the final BVHindices permutation
+    int total = 0, levels = 0;
+    Ctl ctl{};
+    hipEvent_t ev0 = nullptr;
+    char* extra = nullptr;            // caller's scratch inside the pool
+};
+
 #define BVH_HIP(expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
             char m_[384];                                                                         \
             snprintf(m_, sizeof(m_), "pt_bvh_build_device: %s failed: %s", #expr, hipGetErrorString(e_)); \
-            if (pool) (void)hipFree(pool);                                                        \
+            if (B.pool) { (void)hipFree(B.pool); B.pool = nullptr; }                              \
             return pt_fail_(-2, m_);                                                              \
         }                                                                                         \
     } while (0)
 
-}  // namespace
-
-extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
-                                   int max_leaf_size, int mode, pt_bvh_node* nodes_out, int nodes_capacity,
-                                   int32_t* indices_out, pt_bvh_build_stats* stats) {
-    void* pool = nullptr;
-    if (mode != PT_BVH_REFERENCE_TREE) return pt_fail_(-3, "pt_bvh_build_device: only PT_BVH_REFERENCE_TREE (0) is built");
-    if (!positions || !triangles || !nodes_out || !indices_out) return pt_fail_(-1, "pt_bvh_build_device: null argument");
+// Upload, build, number; leaves everything in B (fin nodes in B.A.fin, BVHindices in B.idx). Returns 0 or < 0.
+int build_core(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles, int max_leaf_size,
+               size_t extraBytes, Built& B) {
+    if (!positions || !triangles) return pt_fail_(-1, "pt_bvh_build_device: null argument");
     if (n_triangles <= 0 || n_positions <= 0) return pt_fail_(-1, "pt_bvh_build_device: empty scene (the reference aborts with 'No triangles loaded', main.cu:505-508)");
     if (n_triangles > (1 << 28)) return pt_fail_(-1, "pt_bvh_build_device: more than 2^28 triangles");
     if (max_leaf_size < 0) return pt_fail_(-1, "pt_bvh_build_device: negative leaf size");
@@ -710,20 +779,21 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
             return pt_fail_(-2, m);
         }
     }
-    const auto wall0 = std::chrono::steady_clock::now();
     const int maxBins = n / (max_leaf_size + 1) + 2;
-    Arrays A{};
+    Arrays& A = B.A;
     Carver sizer; carve(sizer, A, n, n_positions, maxBins);
-    BVH_HIP(hipMalloc(&pool, sizer.off + 256));
-    Carver real; real.base = (char*)pool; carve(real, A, n, n_positions, maxBins);
+    const size_t extraOff = (sizer.off + 255) & ~(size_t)255;
+    BVH_HIP(hipMalloc(&B.pool, extraOff + extraBytes + 256));
+    Carver real; real.base = (char*)B.pool; carve(real, A, n, n_positions, maxBins);
+    B.extra = (char*)B.pool + extraOff;
     A.n = n; A.nPos = n_positions;
     hipStream_t st = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    BVH_HIP(hipEventCreate(&ev0)); BVH_HIP(hipEventCreate(&ev1));
+    BVH_HIP(hipEventCreate(&B.ev0));
     BVH_HIP(hipMemcpy((void*)A.pos, positions, sizeof(pt_float4) * (size_t)n_positions, hipMemcpyHostToDevice));
     BVH_HIP(hipMemcpy((void*)A.mesh, triangles, sizeof(pt_triangle) * (size_t)n, hipMemcpyHostToDevice));
 
-    Ctl ctl{};
+    Ctl& ctl = B.ctl;
+    ctl = Ctl{};
     ctl.nextCount = 1; ctl.outCount = 1;
     BVH_HIP(hipMemcpy(A.ctl, &ctl, sizeof(ctl), hipMemcpyHostToDevice));
     WorkNode root{};
@@ -733,7 +803,7 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     const int gN = blocks(n), gScan = blocks(n, kScanTile);
     const int gChunk = std::min(kChunks, gN);
     const int chunk = ((n + gChunk - 1) / gChunk + kBlock - 1) / kBlock * kBlock;      // positions per workgroup, multiple of the tile
-    BVH_HIP(hipEventRecord(ev0, st));
+    BVH_HIP(hipEventRecord(B.ev0, st));
     hipLaunchKernelGGL(k_prims, dim3(gChunk), dim3(kBlock), 0, st, A, chunk);
 
     std::vector<int> levelOff{0};         // out ids of level l are [levelOff[l], levelOff[l+1])
@@ -743,7 +813,7 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     int levels = 0;
     long long bound = 1;                  // upper bound of the level's node count before the host knows it
     for (;;) {
-        if (levels > 4096) { (void)hipFree(pool); return pt_fail_(-4, "pt_bvh_build_device: more than 4096 levels"); }
+        if (levels > 4096) { (void)hipFree(B.pool); B.pool = nullptr; return pt_fail_(-4, "pt_bvh_build_device: more than 4096 levels"); }
         const int gB = blocks(std::min<long long>(bound, n));
         hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, A);
         hipLaunchKernelGGL(k_classify, dim3(gB), dim3(kBlock), 0, st, A, work, max_leaf_size);
@@ -752,7 +822,7 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
         BVH_HIP(hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         if (ctl.bad) {
-            (void)hipFree(pool);
+            (void)hipFree(B.pool); B.pool = nullptr;
             return pt_fail_(ctl.bad == 3 ? -4 : -1, ctl.bad == 1 ? "pt_bvh_build_device: a triangle's vertex index is out of range"
                                           : ctl.bad == 2 ? "pt_bvh_build_device: non-finite vertex position (the reference's tree is undefined for it)"
                                                          : "pt_bvh_build_device: internal error, partition chain did not advance");
@@ -800,7 +870,6 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     }
     // after the last level both index buffers agree on every position (leaves copy, splits scatter)
     const int total = ctl.outCount;
-    if (total > nodes_capacity) { (void)hipFree(pool); return pt_fail_(-1, "pt_bvh_build_device: nodes_out too small (2*n_triangles-1 always suffices)"); }
     const int L = (int)levelOff.size() - 1;
     for (int l = L - 1; l >= 0; l--)
         if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_size, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
@@ -808,17 +877,94 @@ extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, 
     for (int l = 0; l < L; l++)
         if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_pre, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
     hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(kBlock), 0, st, A, total);
-    BVH_HIP(hipEventRecord(ev1, st));
-    BVH_HIP(hipMemcpy(nodes_out, A.fin, sizeof(pt_bvh_node) * (size_t)total, hipMemcpyDeviceToHost));
-    BVH_HIP(hipMemcpy(indices_out, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    B.idx = idx; B.total = total; B.levels = levels;
+    return 0;
+}
+
+void fill_stats(pt_bvh_build_stats* stats, const Built& B, float ms, std::chrono::steady_clock::time_point wall0) {
+    if (!stats) return;
+    stats->n_nodes = B.total; stats->largest_leaf = B.ctl.largestLeaf; stats->backups = B.ctl.backups; stats->depth = B.levels;
+    stats->sort_fallbacks = B.ctl.sortFallbacks; stats->levels = B.levels; stats->device_ms = ms;
+    stats->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+}
+
+}  // namespace
+
+extern "C" int pt_bvh_build_device(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
+                                   int max_leaf_size, int mode, pt_bvh_node* nodes_out, int nodes_capacity,
+                                   int32_t* indices_out, pt_bvh_build_stats* stats) {
+    if (mode != PT_BVH_REFERENCE_TREE) return pt_fail_(-3, "pt_bvh_build_device: only PT_BVH_REFERENCE_TREE (0) is built");
+    if (!nodes_out || !indices_out) return pt_fail_(-1, "pt_bvh_build_device: null argument");
+    const auto wall0 = std::chrono::steady_clock::now();
+    Built B;
+    if (int r = build_core(positions, n_positions, triangles, n_triangles, max_leaf_size, 0, B)) return r;
+    if (B.total > nodes_capacity) { (void)hipFree(B.pool); return pt_fail_(-1, "pt_bvh_build_device: nodes_out too small (2*n_triangles-1 always suffices)"); }
+    hipEvent_t ev1 = nullptr;
+    BVH_HIP(hipEventCreate(&ev1));
+    BVH_HIP(hipEventRecord(ev1, nullptr));
+    BVH_HIP(hipMemcpy(nodes_out, B.A.fin, sizeof(pt_bvh_node) * (size_t)B.total, hipMemcpyDeviceToHost));
+    BVH_HIP(hipMemcpy(indices_out, B.idx, sizeof(int32_t) * (size_t)n_triangles, hipMemcpyDeviceToHost));
     float ms = 0.0f;
-    BVH_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    (void)hipFree(pool);
-    if (stats) {
-        stats->n_nodes = total; stats->largest_leaf = ctl.largestLeaf; stats->backups = ctl.backups; stats->depth = levels;
-        stats->sort_fallbacks = ctl.sortFallbacks; stats->levels = levels; stats->device_ms = ms;
-        stats->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    }
-    return total;
+    BVH_HIP(hipEventElapsedTime(&ms, B.ev0, ev1));
+    (void)hipEventDestroy(B.ev0); (void)hipEventDestroy(ev1);
+    (void)hipFree(B.pool);
+    fill_stats(stats, B, ms, wall0);
+    return B.total;
+}
+
+// Build + re-layout without leaving the device (pt_scene_create_from_mesh, pt_api.hip). d_nodes / d_tris / d_attrs:
+// device buffers for n_triangles PNodes, n_triangles PTris, n_triangles PAttrs. out[0..4] = internal nodes, stack need
+// (internal nodes on the longest root-to-leaf path), root reference, 1 if a triangle uses a material type without a
+// dispatch arm, total reference nodes.
+extern "C" int pt_bvh_build_pack_(const pt_scene_desc* d, const int* mat_types, int max_leaf_size,
+                                  void* d_nodes, void* d_tris, void* d_attrs, int* out5, pt_bvh_build_stats* stats) {
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int n = d->n_triangles;
+    const size_t szNormals = sizeof(pt_float4) * (size_t)std::max(d->n_normals, 1), szUvs = sizeof(pt_float2) * (size_t)std::max(d->n_uvs, 1);
+    const size_t szTypes = sizeof(int) * (size_t)std::max(d->n_materials, 1);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t offUvs = al(szNormals), offTypes = offUvs + al(szUvs), offLeafEnd = offTypes + al(szTypes);
+    const size_t offF = offLeafEnd + al((size_t)n + 16), offS = offF + al(2 * (size_t)n + 16), offBlk = offS + al(sizeof(int) * (2 * (size_t)n + 2));
+    const size_t offFlags = offBlk + al(sizeof(int) * ((size_t)blocks(2LL * n, kScanTile) + 2)), extraBytes = offFlags + 256;
+    Built B;
+    if (int r = build_core(d->positions, d->n_positions, d->triangles, n, max_leaf_size, extraBytes, B)) return r;
+    char* X = B.extra;
+    if (d->n_normals > 0) BVH_HIP(hipMemcpy(X, d->normals, sizeof(pt_float4) * (size_t)d->n_normals, hipMemcpyHostToDevice));
+    if (d->n_uvs > 0) BVH_HIP(hipMemcpy(X + offUvs, d->uvs, sizeof(pt_float2) * (size_t)d->n_uvs, hipMemcpyHostToDevice));
+    BVH_HIP(hipMemcpy(X + offTypes, mat_types, sizeof(int) * (size_t)d->n_materials, hipMemcpyHostToDevice));
+    BVH_HIP(hipMemsetAsync(X + offLeafEnd, 0, (size_t)n + 16, nullptr));
+    BVH_HIP(hipMemsetAsync(X + offFlags, 0, 16, nullptr));
+    PackIn in{(const pt_float4*)X, d->n_normals, (const pt_float2*)(X + offUvs), d->n_uvs, (const int*)(X + offTypes), d->n_materials, d->n_lights};
+    unsigned char* leafEnd = (unsigned char*)(X + offLeafEnd);
+    int* flags = (int*)(X + offFlags);
+    // internal nodes in breadth-first order: exclusive scan of "is internal" over the builder's records
+    Arrays S = B.A;                                      // the scan kernels read F / S / blockSum / n from their Arrays
+    S.F = (unsigned char*)(X + offF); S.S = (int*)(X + offS); S.blockSum = (int*)(X + offBlk); S.n = B.total;
+    hipStream_t st = nullptr;
+    const int gT = blocks(B.total), gScan = blocks(B.total, kScanTile);
+    hipLaunchKernelGGL(k_pack_flags, dim3(gT), dim3(kBlock), 0, st, B.A, B.total, S.F);
+    hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, S, 0);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, S, gScan, 0);
+    hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, S, 0);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(gT), dim3(kBlock), 0, st, B.A, B.total, S.S, (pt::PNode*)d_nodes, leafEnd);
+    hipLaunchKernelGGL(k_pack_tris, dim3(blocks(n)), dim3(kBlock), 0, st, B.A, B.idx, in, leafEnd, (pt::PTri*)d_tris, flags);
+    hipLaunchKernelGGL(k_pack_attrs, dim3(blocks(n)), dim3(kBlock), 0, st, B.A, in, (pt::PAttr*)d_attrs, flags);
+    hipEvent_t ev1 = nullptr;
+    BVH_HIP(hipEventCreate(&ev1));
+    BVH_HIP(hipEventRecord(ev1, st));
+    int nInternal = 0, fl = 0;
+    OutNode rootRec{};
+    BVH_HIP(hipMemcpy(&nInternal, S.S + B.total, sizeof(int), hipMemcpyDeviceToHost));
+    BVH_HIP(hipMemcpy(&fl, flags, sizeof(int), hipMemcpyDeviceToHost));
+    BVH_HIP(hipMemcpy(&rootRec, B.A.out, sizeof(OutNode), hipMemcpyDeviceToHost));
+    float ms = 0.0f;
+    BVH_HIP(hipEventElapsedTime(&ms, B.ev0, ev1));
+    (void)hipEventDestroy(B.ev0); (void)hipEventDestroy(ev1);
+    (void)hipFree(B.pool); B.pool = nullptr;
+    if (fl & 1) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's material index is out of range");
+    if (fl & 2) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's normal index is out of range (faces without vn must be given a normal by the loader)");
+    if (fl & 4) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's uv index is out of range");
+    out5[0] = nInternal; out5[1] = B.levels - 1; out5[2] = rootRec.count > 0 ? ~rootRec.first : 0; out5[3] = (fl & 0x100) ? 1 : 0; out5[4] = B.total;
+    fill_stats(stats, B, ms, wall0);
+    return 0;
 }

@@ -19,6 +19,7 @@
 #ifndef PT_API_H
 #define PT_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -209,6 +210,14 @@ typedef struct pt_bvh_build_stats {
 int pt_bvh_build_device(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
                         int max_leaf_size, int mode, pt_bvh_node* nodes_out, int nodes_capacity,
                         int32_t* indices_out, pt_bvh_build_stats* stats);
+/* The same, without leaving the device: builds the reference tree from desc->positions / triangles (desc->bvh and
+ * desc->bvh_indices are ignored and may be NULL) and lays out the traversal records there — what main.cu:524-557
+ * (buildBVH + uploads) becomes when the geometry is large. The scene renders exactly like one made by
+ * pt_scene_create from the host-built tree. */
+pt_scene* pt_scene_create_from_mesh(const pt_scene_desc* desc, int max_leaf_size, pt_bvh_build_stats* stats);
+/* Test hook: copy the packed traversal records back (what: 0 nodes 64 B, 1 triangles 48 B, 2 attributes 80 B);
+ * returns the record count. */
+int pt_debug_packed(pt_scene* scene, int what, void* dst, size_t capacity_bytes);
 int novum_bvh_build_host(const pt_float4* positions, int n_positions, const pt_triangle* triangles, int n_triangles,
                          int max_leaf_size, pt_bvh_node* nodes_out, int nodes_capacity,
                          int32_t* indices_out, pt_bvh_build_stats* stats);

@@ -1,6 +1,8 @@
 """BVH builder parity. The oracle's buildBVH (oracle/oracle_scene.cpp, following
 main.cu:20-233) is the checker; the kept host builder (novum_bvh_build_host) and the device builder
 (pt_bvh_build_device, reference-tree mode) must give its node array and BVHindices byte for byte."""
+import os
+
 import numpy as np
 import pytest
 
@@ -112,3 +114,50 @@ def test_device_builder_large_scenes(api, oracle, gpu_ready, scene_dir):
         assert np.array_equal(dn, hs.array("bvh")) and np.array_equal(di, hs.array("indices").view(np.int32))
         assert dst["largest_leaf"] == hs.info["largest_leaf"] and dst["backups"] == hs.info["backup_count"]
         hs.close()
+
+
+def _walk(nodes, ref, out):
+    """Canonical depth-first listing of a packed tree: PNode numbering is any breadth-first order, the tree is not."""
+    stack = [ref]
+    f = nodes.view(np.float32).reshape(-1, 16); i = nodes.view(np.int32).reshape(-1, 16)
+    while stack:
+        r = stack.pop()
+        if r < 0:
+            out.append(("leaf", int(~r)))
+            continue
+        out.append(("node", f[r, :12].tobytes()))
+        stack.append(int(i[r, 13])); stack.append(int(i[r, 12]))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cornell32", "mixed32", "textured32", "blob", "atrium"])
+def test_device_relayout_matches_host_relayout(api, oracle, gpu_ready, scene_dir, scene):
+    """pt_scene_create_from_mesh (tree built and laid out on the device) against pt_scene_create on the host-built
+    tree: packed triangles and attributes byte for byte, the packed tree node for node, and the same render."""
+    from cudapathtracer_amd import scenes
+    if scene == "blob":
+        cfg = scenes.blob_in_box(os.path.join(scene_dir, "rl_blob"), 48, 32, 2, 5, subdiv=4, name="rl_blob")["config"]
+    elif scene == "atrium":
+        cfg = scenes.atrium(os.path.join(scene_dir, "rl_atrium"), 48, 32, 2, 6, name="rl_atrium")["config"]
+    else:
+        cfg = golden_scene(scene, "scenes_tex" if scene.startswith("textured") else "scenes")
+    hs = api.HostScene(cfg)
+    a, b = api.Scene(hs), api.Scene.from_mesh(hs)
+    assert np.array_equal(a.packed("tris"), b.packed("tris"))
+    assert np.array_equal(a.packed("attrs"), b.packed("attrs"))
+    na, nb = a.packed("nodes"), b.packed("nodes")
+    assert na.shape == nb.shape
+    root = 0 if len(na) else -1
+    if len(na):
+        assert _walk(na, root, []) == _walk(nb, root, [])
+    assert b.build_stats["n_nodes"] == hs.info["n_nodes"] and b.build_stats["largest_leaf"] == hs.info["largest_leaf"]
+    i = hs.info
+    w, h = min(i["width"], 48), min(i["height"], 32)
+    cam = api.Camera.Pinhole((0, 0, 1), w, h)
+    ca, cnta = a.render(cam, w, h, 2, 5, counters=True)
+    cb, cntb = b.render(cam, w, h, 2, 5, counters=True)
+    assert np.array_equal(cnta, cntb)
+    assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
+    ta, _ = a.render(cam, w, h, 2, 5); tb, _ = b.render(cam, w, h, 2, 5)
+    assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)) and np.array_equal(ta.view(np.uint32), ca.view(np.uint32))
