@@ -161,3 +161,19 @@ def test_device_relayout_matches_host_relayout(api, oracle, gpu_ready, scene_dir
     assert np.array_equal(ca.view(np.uint32), cb.view(np.uint32))
     ta, _ = a.render(cam, w, h, 2, 5); tb, _ = b.render(cam, w, h, 2, 5)
     assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)) and np.array_equal(ta.view(np.uint32), ca.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_relayout_rejects_bad_indices(api, gpu_ready):
+    """Out-of-range material / normal / uv / vertex indices are errors, not out-of-bounds reads, on the device path too."""
+    import ctypes
+    hs = api.HostScene(golden_scene("cornell32"))
+    for field, col, needle in (("material", 9, "material"), ("normal", 3, "normal"), ("uv", 6, "uv"), ("vertex", 0, "vertex index")):
+        mesh = hs.array("mesh").view(np.int32).reshape(-1, 20).copy()
+        mesh[2, col] = 10**6
+        d = api.SceneDesc.from_buffer_copy(hs.desc)
+        d.triangles = mesh.ctypes.data
+        with pytest.raises(api.PtError, match=needle):
+            h = api.lib().pt_scene_create_from_mesh(ctypes.byref(d), 2, None)
+            if not h:
+                raise api.PtError(api.lib().pt_last_error().decode())
