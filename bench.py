@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="megakernel", choices=["megakernel", "wavefront"],
                     help="kernel organisation (SURVEY §8 f-1 A/B); the headline is the megakernel")
+    ap.add_argument("--culling", action="store_true",
+                    help="diagnostic: opt-in box culling (pt_set_culling) - NOT the reference's visiting set, never the headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,6 +134,10 @@ def main():
     spp = args.spp or info["spp"]
     cam = host.camera()
     scene = api.Scene(host).set_variant(args.variant)           # scene resident in HBM from here on
+    if args.culling:
+        scene.set_culling(True)
+    if args.culling:
+        scene.set_culling(True)
 
     tr = api.rank_tiles(w, h, rank, world)
     pad = D.padded_tile_count(w, h, world)
@@ -189,7 +195,8 @@ def main():
             "msample_per_s": n_px * spp * args.steps / elapsed / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp,
+            "config": {"workload": (args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp) +
+                                   (" [opt-in box culling: not the reference's visiting set]" if args.culling else ""),
                        "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "variant": args.variant, "seed": api.SEED,
                        "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},

@@ -113,6 +113,7 @@ def lib():
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
     L.pt_scene_flags.argtypes = [vp]
+    L.pt_set_culling.argtypes = [vp, i32]
     L.pt_debug_stamps.argtypes = [vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
@@ -378,9 +379,14 @@ class Scene:
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
         return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end"), (int(v) for v in out)))
 
+    def set_culling(self, on=True):
+        """pt_set_culling: opt-in box culling (not the reference's visiting set; see pt_api.h)."""
+        _check(lib().pt_set_culling(self.h, int(bool(on))), "pt_set_culling")
+        return self
+
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16)}
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

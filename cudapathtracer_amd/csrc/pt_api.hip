@@ -65,6 +65,7 @@ struct pt_scene {
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
+    bool cull = false;                    // pt_set_culling / PT_CULL=1: opt-in, not parity-exact by construction
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
     bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
@@ -313,6 +314,7 @@ static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_
     if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
     if (const char* e = getenv("PT_WAVES_HBM")) { s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && e[0] == '2'; }
     if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
+    if (const char* e = getenv("PT_CULL")) s->cull = (e[0] == '1');
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
     if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = atoi(e);     // 0 off, 1 once no fresh tile is left, 2 always
@@ -461,6 +463,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
+    P.cull = (s->cull && hbm) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -623,13 +626,19 @@ static int queue_error(pt_scene* s) {
     return 0;
 }
 
+int pt_set_culling(pt_scene* s, int on) {
+    if (!s) return fail(-1, "null scene");
+    s->cull = on != 0;
+    return 0;
+}
+
 int pt_scene_flags(pt_scene* s) {
     if (!s) return 0;
     const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

@@ -172,7 +172,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false>
 PT_DEV void megakernel_body(const KParams& P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
@@ -237,7 +237,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP>(S, SC, ro, wi, maxt, st, c); };
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c); };
 
 #ifdef PT_STAMPS
     unsigned long long stamp[3] = {0, 0, 0};
@@ -309,7 +309,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
-        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
+        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
         PT_STAMP(1);
     }
 
@@ -372,9 +372,9 @@ __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_M
 #endif
 megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds>(P); }
 
-template <int INTEG, bool COUNT>
+template <int INTEG, bool COUNT, bool CULL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
-megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm>(P); }
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL>(P); }
 
 // -------------------------------------------------------------------------------------------
 // tile-major [local tile][64] <-> scan-line colors[y*w+x]
@@ -525,7 +525,8 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
     const bool hbm = P.wavesPerSimd == kWavesHbm;              // chosen by the host together with the spill layout
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : kStackLds);
 #define PT_LAUNCH_MK(I, C, D, O) hipLaunchKernelGGL((megakernel<I, C, D, O>), grid, block, lds, stream, P)
-#define PT_LAUNCH_HBM(I, C) hipLaunchKernelGGL((megakernel_hbm<I, C>), grid, block, lds, stream, P)
+#define PT_LAUNCH_HBM(I, C) do { if (P.cull) hipLaunchKernelGGL((megakernel_hbm<I, C, true>), grid, block, lds, stream, P); \
+                                 else hipLaunchKernelGGL((megakernel_hbm<I, C, false>), grid, block, lds, stream, P); } while (0)
 #define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
                               else if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, true, false, false); } \
                               else { if (P.onchip) PT_LAUNCH_MK(I, false, false, true); else PT_LAUNCH_MK(I, false, false, false); } } while (0)

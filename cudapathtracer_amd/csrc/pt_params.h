@@ -30,6 +30,7 @@ struct KParams {
     int w, h, spp, maxDepth, useMIS;
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
+    int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
     int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)

@@ -409,6 +409,36 @@ def test_fuzz_scenes(api, oracle, gpu_ready, scene_dir, seed):
         assert_bits_equal(wf, ocol, "fuzz %d, wavefront" % seed)
 
 
+def test_opt_in_culling(api, gpu_ready, scene_dir, monkeypatch):
+    """pt_set_culling is NOT the reference's visiting set (pt_api.h) and is off by default: at full scale it changes
+    about 3 pixels per 1e9 rays (tools/cull_experiment.py). What this test pins is the plumbing: at the scale of the
+    golden scenes, eight random scenes and a small frame of the 263 k-triangle atrium the image is the same bit for
+    bit while fewer boxes are tested. Forced onto the kernel for scenes in HBM (the only one with the instantiation)."""
+    from cudapathtracer_amd import scenes
+    monkeypatch.setenv("PT_ONCHIP", "0"); monkeypatch.setenv("PT_WAVES_HBM", "2")
+    cfgs = [golden_case_scene(np.load(os.path.join(GOLDEN, c + ".npz"))) for c in CASES]
+    cfgs += [scenes.fuzz(os.path.join(scene_dir, "cfuzz%d" % k), k)["config"] for k in range(8)]
+    cfgs.append(scenes.atrium(os.path.join(scene_dir, "catrium"), 96, 54, 4, 8, name="catrium")["config"])
+    fewer = 0
+    for cfg in cfgs:
+        hs = api.HostScene(cfg)
+        sc = api.Scene(hs)
+        i = hs.info
+        exact, ce = sc.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], counters=True)
+        assert not sc.flags()["culling"]
+        sc.set_culling(True)
+        culled, cc = sc.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], counters=True)
+        timed, _ = sc.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"])
+        assert sc.flags()["culling"]
+        assert_bits_equal(culled, exact, "culled vs exact, %s" % cfg)
+        assert_bits_equal(timed, exact, "culled timed kernel vs exact, %s" % cfg)
+        assert np.array_equal(cc[..., [0, 1, 5, 6, 7]], ce[..., [0, 1, 5, 6, 7]])          # rays, hits, draws, iterations: unchanged
+        assert np.all(cc[..., 3] <= ce[..., 3]) and np.all(cc[..., 4] <= ce[..., 4])        # boxes, triangles: never more
+        fewer += int(ce[..., 3].sum() - cc[..., 3].sum())
+        sc.close()
+    assert fewer > 0
+
+
 def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
     """Camera::NotPinhole (objects.cuh:237-264): aperture 0.08, focal distance 2.2, rotated — through the full loop."""
     from cudapathtracer_amd import scenes
