@@ -198,7 +198,7 @@ def main():
             "config": {"workload": (args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp) +
                                    (" [opt-in box culling: not the reference's visiting set]" if args.culling else ""),
                        "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "variant": args.variant, "seed": api.SEED,
-                       "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
+                       "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "kernel_flags": scene.flags(), "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, spp) if (world == 1 and args.variant == "megakernel") else None,
