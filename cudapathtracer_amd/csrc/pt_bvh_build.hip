@@ -57,8 +57,12 @@ constexpr int kStageMin = 4096;       // nodes at least this large accumulate in
 constexpr int kChunks = 1024;         // workgroups of the per-position accumulation passes
 constexpr int kSortSmall = 1024;      // median fallback: rank-by-counting up to here, bitonic network above
 constexpr int kSortTile = 2048;       // keys one workgroup sorts in LDS
+#ifndef PT_BVH_SMALL
+#define PT_BVH_SMALL 64
+#endif
+constexpr int kSmallNode = PT_BVH_SMALL;   // a node of at most this many primitives (<= 64) is finished, whole subtree, by ONE WAVE; 0 = off
 
-enum : int { ST_LEAF = 1, ST_SPLITTING = 2, ST_SORT = 3, ST_OK = 4, ST_REDO = 5 };
+enum : int { ST_LEAF = 1, ST_SPLITTING = 2, ST_SORT = 3, ST_OK = 4, ST_REDO = 5, ST_SMALL = 6 };
 
 struct WorkNode {                 // 64 B, one per node of the level being built
     int start, end, out, axis;
@@ -68,9 +72,10 @@ struct WorkNode {                 // 64 B, one per node of the level being built
     int pad;
 };
 struct Bins { unsigned lo[NB][3], hi[NB][3]; int cnt[NB]; };
-struct OutNode { float lo[3], hi[3]; int left, right, first, count, size, pre; };
+struct OutNode { float lo[3], hi[3]; int left, right, first, count, size, pre, sub, height, subInternal, pad; };   // sub >= 0: root of a subtree in Arrays::sub
+struct SubNode { float lo[3], hi[3]; int left, right, first, count; };                                          // children as indices local to the subtree (pre-order)
 struct SortRec { int w, start, end, axis; };
-struct Ctl { int curCount, nextCount, outCount, binCount, anyRedo, redoCount, sortCount, sortMax, largestLeaf, backups, sortFallbacks, bad; };
+struct Ctl { int curCount, nextCount, outCount, binCount, anyRedo, redoCount, sortCount, sortMax, largestLeaf, backups, sortFallbacks, bad, subCount; };
 
 __host__ __device__ inline unsigned fkey(float f) {
     unsigned u;
@@ -110,6 +115,7 @@ struct Arrays {
     OutNode* out;
     pt_bvh_node* fin;
     SortRec* sortRec;
+    SubNode* sub;
     unsigned long long* keys;
     Ctl* ctl;
 };
@@ -273,6 +279,7 @@ __global__ void k_classify(Arrays A, WorkNode* work, int leafMax) {
     OutNode& o = A.out[nd.out];
     float mn[3], mx[3];
     for (int k = 0; k < 3; k++) { mn[k] = funkey(nd.lo[k]); mx[k] = funkey(nd.hi[k]); o.lo[k] = mn[k]; o.hi[k] = mx[k]; }
+    o.sub = -1; o.height = 1; o.subInternal = 0;
     int n = nd.end - nd.start;
     if (n <= leafMax) {
         o.first = nd.start; o.count = n; o.left = o.right = -1;
@@ -280,6 +287,7 @@ __global__ void k_classify(Arrays A, WorkNode* work, int leafMax) {
         atomicMax(&A.ctl->largestLeaf, n);
         return;
     }
+    if (n <= kSmallNode) { work[w].state = ST_SMALL; return; }      // k_subtree finishes the whole subtree
     float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
     int axis = (dy > dx && dy > dz) ? 1 : ((dz > dx && dz > dy) ? 2 : 0);
     int b = atomicAdd(&A.ctl->binCount, 1);
@@ -326,13 +334,9 @@ __device__ inline float area_keys(const unsigned lo[3], const unsigned hi[3]) { 
     return 2.0f * (dx * dy + dx * dz + dy * dz);
 }
 
-// Cost sweep, main.cu:87-131. Right side: bucket i is counted twice (:102-109), kept.
-__global__ void k_sah(Arrays A, WorkNode* work) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= A.ctl->curCount) return;
-    if (work[w].state != ST_SPLITTING) return;
-    WorkNode nd = work[w];
-    const Bins& B = A.bins[nd.bin];
+// Cost sweep, main.cu:87-131. Right side: bucket i is counted twice (:102-109), kept. Returns the best
+// bucket boundary or -1.
+__device__ inline int sah_sweep(const Bins& B, const unsigned nlo[3], const unsigned nhi[3]) {
     unsigned rlo[NB][3], rhi[NB][3]; int rc[NB];
     int suffix = B.cnt[NB - 1];
     for (int k = 0; k < 3; k++) { rlo[NB - 1][k] = B.lo[NB - 1][k]; rhi[NB - 1][k] = B.hi[NB - 1][k]; }
@@ -342,7 +346,7 @@ __global__ void k_sah(Arrays A, WorkNode* work) {
         suffix += B.cnt[i];
         rc[i] = B.cnt[i] + suffix;
     }
-    const float whole = area_keys(nd.lo, nd.hi);
+    const float whole = area_keys(nlo, nhi);
     unsigned llo[3], lhi[3]; int lc = B.cnt[0];
     for (int k = 0; k < 3; k++) { llo[k] = B.lo[0][k]; lhi[k] = B.hi[0][k]; }
     float best = FLT_MAX; int bestI = -1;
@@ -352,6 +356,14 @@ __global__ void k_sah(Arrays A, WorkNode* work) {
         for (int k = 0; k < 3; k++) { llo[k] = umin_(llo[k], B.lo[i][k]); lhi[k] = umax_(lhi[k], B.hi[i][k]); }
         lc += B.cnt[i];
     }
+    return bestI;
+}
+__global__ void k_sah(Arrays A, WorkNode* work) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= A.ctl->curCount) return;
+    if (work[w].state != ST_SPLITTING) return;
+    WorkNode nd = work[w];
+    const int bestI = sah_sweep(A.bins[nd.bin], nd.lo, nd.hi);
     if (bestI < 0) {
         work[w].state = ST_SORT;
         A.sortRec[atomicAdd(&A.ctl->sortCount, 1)] = SortRec{w, nd.start, nd.end, nd.axis};
@@ -360,6 +372,152 @@ __global__ void k_sah(Arrays A, WorkNode* work) {
     } else {
         float a0 = funkey(nd.lo[nd.axis]), ext = funkey(nd.hi[nd.axis]) - a0;
         work[w].split = a0 + ext * (float(bestI) / float(NB));
+    }
+}
+
+// ---- small subtrees: one wave each ----------------------------------------------------------------
+// A node of at most 64 primitives is finished, down to its leaves, by ONE WAVE holding one primitive per lane: the
+// reference's recursion (buildBVH, main.cu:133-233) node by node in its own pre-order (explicit stack, right pushed
+// before left, as novum_host.cpp does), every step a wave-level operation — bounds and buckets by masked min/max
+// reductions on the order-preserving keys, the sweep on the 12 buckets, the Lomuto partition in its closed form on a
+// ballot, the median fallback as a rank-by-counting over the lanes, the centroid mean as a serial sum over lanes in
+// position order. No atomics on nodes, no launches, no global traffic but the first load and the last store. The
+// deep levels of a tree, where nodes hold a handful of primitives, cost the level-synchronous passes the most.
+struct SubStack { short s, e, parent, depthLeft; };             // range relative to the subtree; depthLeft = depth * 2 + isLeft
+struct SubLds { Bins bins; SubStack stack[65]; };              // per-wave scratch: every lane writes the same values, then reads them back
+__device__ inline int select64(unsigned long long m, int k) {      // position of the k-th (0-based) set bit of m
+    int pos = 0;
+    for (int w = 32; w; w >>= 1) {
+        const unsigned long long low = m & ((1ull << w) - 1ull);
+        const int c = (int)__popcll(low);
+        if (k >= c) { k -= c; m >>= w; pos += w; } else m = low;
+    }
+    return pos;
+}
+__device__ inline unsigned wmin_if(bool c, unsigned v) { return wave_min(c ? v : 0xffffffffu); }
+__device__ inline unsigned wmax_if(bool c, unsigned v) { return wave_max(c ? v : 0u); }
+__global__ __launch_bounds__(kBlock) void k_subtree(Arrays A, WorkNode* work, int* idx, int leafMax) {
+    __shared__ SubLds lds[kBlock / 64];
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int w = blockIdx.x * (kBlock / 64) + wv;
+    if (w >= A.ctl->curCount) return;                           // wave-uniform
+    if (work[w].state != ST_SMALL) return;
+    SubLds& L = lds[wv];
+    const int s0 = work[w].start, n0 = work[w].end - s0;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&A.ctl->subCount, 2 * n0 - 1);
+    SubNode* sub = A.sub + __shfl(base, 0);
+    // one primitive per lane (lanes >= n0 idle); the data moves between lanes as the ranges are permuted
+    int id = lane < n0 ? idx[s0 + lane] : 0;
+    float c3[3] = {0.0f, 0.0f, 0.0f};
+    unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
+    if (lane < n0) {
+        c3[0] = A.cx[id]; c3[1] = A.cy[id]; c3[2] = A.cz[id];
+        const float4 l = A.lo[id], h = A.hi[id];
+        kl[0] = fkey(l.x); kl[1] = fkey(l.y); kl[2] = fkey(l.z); kh[0] = fkey(h.x); kh[1] = fkey(h.y); kh[2] = fkey(h.z);
+    }
+    int top = 0, nLocal = 0, nInternal = 0, height = 0, largest = 0, backups = 0, sorts = 0;
+    L.stack[0] = SubStack{0, (short)n0, -1, 2};
+    top = 1;
+    auto permute = [&](int dest) {                              // lane's data goes to lane `dest` (a permutation of the lanes): ds_permute
+        const int a = dest << 2;
+        id = __builtin_amdgcn_ds_permute(a, id);
+        for (int k = 0; k < 3; k++) {
+            c3[k] = __int_as_float(__builtin_amdgcn_ds_permute(a, __float_as_int(c3[k])));
+            kl[k] = (unsigned)__builtin_amdgcn_ds_permute(a, (int)kl[k]);
+            kh[k] = (unsigned)__builtin_amdgcn_ds_permute(a, (int)kh[k]);
+        }
+    };
+    int guard = 0;                                             // every loop below is bounded by construction; the guards turn a logic
+    while (top > 0) {                                          // error into ctl->bad = 4 instead of a spinning wave
+        if (++guard > 2 * 64 + 2 || top > 64) { if (lane == 0) A.ctl->bad = 4; break; }
+        const SubStack j = L.stack[--top];
+        const int s = j.s, e = j.e, n = e - s, depth = j.depthLeft >> 1, nodeId = nLocal++;
+        const bool in = lane >= s && lane < e;
+        if (lane == 0 && j.parent >= 0) { if (j.depthLeft & 1) sub[j.parent].left = nodeId; else sub[j.parent].right = nodeId; }
+        unsigned nlo[3], nhi[3];
+        for (int k = 0; k < 3; k++) { nlo[k] = wmin_if(in, kl[k]); nhi[k] = wmax_if(in, kh[k]); }
+        bool isLeaf = n <= leafMax;
+        int mid = s;
+        if (!isLeaf) {
+            const float mnx = funkey(nlo[0]), mny = funkey(nlo[1]), mnz = funkey(nlo[2]);
+            const float dx = funkey(nhi[0]) - mnx, dy = funkey(nhi[1]) - mny, dz = funkey(nhi[2]) - mnz;
+            const int axis = (dy > dx && dy > dz) ? 1 : ((dz > dx && dz > dy) ? 2 : 0);
+            const float c = axis == 0 ? c3[0] : (axis == 1 ? c3[1] : c3[2]);
+            const float a0 = funkey(nlo[axis]), ext = funkey(nhi[axis]) - a0;
+            // buckets, main.cu:71-85
+            {
+                const unsigned kmax = fkey(FLT_MAX), kmin = fkey(-FLT_MAX);
+                if (lane < NB * 3) { (&L.bins.lo[0][0])[lane] = kmax; (&L.bins.hi[0][0])[lane] = kmin; }
+                if (lane < NB) L.bins.cnt[lane] = 0;
+            }
+            float q = NB * (c - a0) / ext;
+            int b = (q == q && fabsf(q) < 1e9f) ? (int)q : 0;
+            b = b < 0 ? 0 : (b > NB - 1 ? NB - 1 : b);
+            // one LDS atomic per box word and lane (min / max / add are exact in any order); the wavefront-scope
+            // fences keep the initialising stores, the atomics and the sweep's loads in that order for the compiler
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (in) {
+                for (int k = 0; k < 3; k++) { atomicMin(&L.bins.lo[b][k], kl[k]); atomicMax(&L.bins.hi[b][k], kh[k]); }
+                atomicAdd(&L.bins.cnt[b], 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int bestI = sah_sweep(L.bins, nlo, nhi);      // every lane, same data
+            float split;
+            if (bestI < 0) {                                    // median fallback: order by (centroid, index)
+                sorts++;
+                int rank = 0;
+                for (int k = s; k < e; k++) {
+                    const float ck = __shfl(c, k); const int ik = __shfl(id, k);
+                    rank += (ck < c || (!(c < ck) && ik < id)) ? 1 : 0;
+                }
+                permute(in ? s + rank : lane);
+                const float cc = axis == 0 ? c3[0] : (axis == 1 ? c3[1] : c3[2]);
+                split = __shfl(cc, (s0 + s + s0 + e) / 2 - s0);
+            } else split = a0 + ext * (float(bestI) / float(NB));
+            for (int attempt = 0; attempt < 2; attempt++) {
+                const float cc = axis == 0 ? c3[0] : (axis == 1 ? c3[1] : c3[2]);
+                const bool good = in && cc < split;
+                const unsigned long long G = __ballot(good);
+                const int nl = (int)__popcll(G);
+                if (nl > 0 && nl < n - 1) {                     // partitionPrimitives, main.cu:49-62, closed form (file header)
+                    const int rank = (int)__popcll(G & ((1ull << lane) - 1ull));
+                    // position of the k-th element below the split = k-th set bit of G: pure ALU, no table
+                    int dest = good ? s + rank : lane;
+                    if (in && !good) { for (int hops = 0; dest - s < nl && hops < 64; hops++) dest = select64(G, dest - s); }
+                    permute(dest);
+                    mid = s + nl;
+                    break;                                      // (the reference's second count + partition is a no-op)
+                } else if (attempt == 0) {                      // centroid-mean retry, main.cu:192-202: serial sum in position order
+                    backups++;
+                    float sum = 0.0f;
+                    for (int k = s; k < e; k++) sum += __shfl(cc, k);
+                    split = sum / n;
+                } else isLeaf = true;                           // forced, possibly oversize, leaf
+            }
+        }
+        if (lane == 0) {
+            SubNode nd;
+            for (int k = 0; k < 3; k++) { nd.lo[k] = funkey(nlo[k]); nd.hi[k] = funkey(nhi[k]); }
+            nd.left = nd.right = -1;
+            if (isLeaf) { nd.first = s0 + s; nd.count = n; } else { nd.first = -1; nd.count = 0; }
+            sub[nodeId] = nd;
+        }
+        if (!isLeaf) {                                          // all lanes, same values
+            L.stack[top] = SubStack{(short)mid, (short)e, (short)nodeId, (short)((depth + 1) * 2)};          // right: after the whole left subtree
+            L.stack[top + 1] = SubStack{(short)s, (short)mid, (short)nodeId, (short)((depth + 1) * 2 + 1)};
+        }
+        if (isLeaf) { largest = largest > n ? largest : n; height = height > depth ? height : depth; }
+        else { top += 2; nInternal++; }
+    }
+    if (lane < n0) idx[s0 + lane] = id;
+    if (lane == 0) {
+        OutNode& o = A.out[work[w].out];
+        o.sub = (int)(sub - A.sub); o.size = nLocal; o.height = height; o.subInternal = nInternal;
+        o.left = o.right = -1; o.first = -1; o.count = 0;
+        atomicMax(&A.ctl->largestLeaf, largest);
+        if (backups) atomicAdd(&A.ctl->backups, backups);
+        if (sorts) atomicAdd(&A.ctl->sortFallbacks, sorts);
     }
 }
 
@@ -598,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(Arrays A, const WorkNode* wo
         bool act = st == ST_OK, big = false;
         int side = 0;
         unsigned kl[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, kh[3] = {0u, 0u, 0u};
-        if (st == ST_LEAF) { idxOut[p] = idx[p]; nodeOut[p] = -1; nodeOf[p] = -1; }
+        if (st == ST_LEAF || st == ST_SMALL) { idxOut[p] = idx[p]; nodeOut[p] = -1; nodeOf[p] = -1; }
         if (act) {
             const WorkNode& nd = work[w];
             int s = nd.start, nl = nd.numLeft, id = idx[p], dst;
@@ -628,13 +786,17 @@ __global__ void k_size(Arrays A, int a, int b) {
     int o = a + blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= b) return;
     OutNode& n = A.out[o];
-    n.size = n.count > 0 ? 1 : 1 + A.out[n.left].size + A.out[n.right].size;
+    if (n.sub >= 0) return;                                     // size and height set by k_subtree
+    if (n.count > 0) { n.size = 1; n.height = 1; return; }
+    const OutNode &l = A.out[n.left], &r = A.out[n.right];
+    n.size = 1 + l.size + r.size;
+    n.height = 1 + (l.height > r.height ? l.height : r.height);
 }
 __global__ void k_pre(Arrays A, int a, int b) {
     int o = a + blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= b) return;
     const OutNode& n = A.out[o];
-    if (n.count > 0) return;
+    if (n.count > 0 || n.sub >= 0) return;
     A.out[n.left].pre = n.pre + 1;
     A.out[n.right].pre = n.pre + 1 + A.out[n.left].size;
 }
@@ -642,6 +804,18 @@ __global__ void k_emit(Arrays A, int total) {
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= total) return;
     const OutNode& n = A.out[o];
+    if (n.sub >= 0) {                                           // a subtree: its nodes are already in pre-order
+        const SubNode* s = A.sub + n.sub;
+        for (int j = 0; j < n.size; j++) {
+            pt_bvh_node f;
+            f.aabbMIN = pt_float4{s[j].lo[0], s[j].lo[1], s[j].lo[2], 0.0f};
+            f.aabbMAX = pt_float4{s[j].hi[0], s[j].hi[1], s[j].hi[2], 0.0f};
+            if (s[j].count > 0) { f.left = f.right = -1; f.first = s[j].first; f.primCount = s[j].count; }
+            else { f.left = n.pre + s[j].left; f.right = n.pre + s[j].right; f.first = -1; f.primCount = 0; }
+            A.fin[n.pre + j] = f;
+        }
+        return;
+    }
     pt_bvh_node f;
     f.aabbMIN = pt_float4{n.lo[0], n.lo[1], n.lo[2], 0.0f};
     f.aabbMAX = pt_float4{n.hi[0], n.hi[1], n.hi[2], 0.0f};
@@ -671,6 +845,7 @@ void carve(Carver& c, Arrays& A, int n, int nPos, int maxBins) {
     A.blockSum = c.take<int>((size_t)blocks(n, kScanTile) + 1);
     A.redoList = c.take<int>(maxBins);
     A.sortRec = c.take<SortRec>(maxBins);
+    A.sub = c.take<SubNode>(2 * (size_t)n + 2);
     A.keys = c.take<unsigned long long>(2 * (size_t)n + kSortTile);
     A.F = c.take<unsigned char>((size_t)n + 16);
     A.workA = c.take<WorkNode>((size_t)n + 2); A.workB = c.take<WorkNode>((size_t)n + 2);
@@ -683,20 +858,49 @@ void carve(Carver& c, Arrays& A, int n, int nPos, int maxBins) {
 // builder's arrays. Same contents as pt_api.hip's host re-pack; PNodes are numbered in the builder's
 // breadth-first order (children of one level in allocation order, which is any valid breadth-first order).
 struct PackIn { const pt_float4* normals; int nNormals; const pt_float2* uvs; int nUvs; const int* matType; int nMats; int nLights; };
-__global__ void k_pack_flags(Arrays A, int total, unsigned char* F) {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < total) F[o] = A.out[o].count > 0 ? 0 : 1;
-}
-__global__ void k_pack_nodes(Arrays A, int total, const int* iid, pt::PNode* nodes, unsigned char* leafEnd) {
+// mode 0: F = record is an internal node of the breadth-first part; mode 1: F = internal nodes inside the record's subtree
+__global__ void k_pack_flags(Arrays A, int total, unsigned char* F, int mode) {
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= total) return;
     const OutNode& n = A.out[o];
+    F[o] = mode == 0 ? ((n.count > 0 || n.sub >= 0) ? 0 : 1) : (n.sub >= 0 ? (unsigned char)n.subInternal : 0);
+}
+// Reference of record c as a child: leaf -> ~first; breadth-first internal -> its number; subtree -> its root's number
+// (the subtrees' internal nodes are numbered after all breadth-first ones: nBfs + base of the subtree + local number).
+__device__ inline int pack_ref(const Arrays& A, int c, const int* iid, const int* subBase, int nBfs) {
+    const OutNode& n = A.out[c];
+    if (n.sub >= 0) { const SubNode& r = A.sub[n.sub]; return r.count > 0 ? ~r.first : nBfs + subBase[c]; }
+    return n.count > 0 ? ~n.first : iid[c];
+}
+__global__ void k_pack_nodes(Arrays A, int total, const int* iid, const int* subBase, pt::PNode* nodes, unsigned char* leafEnd) {
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int nBfs = iid[total];
+    const OutNode& n = A.out[o];
+    if (n.sub >= 0) {                                           // a subtree: walk its pre-order list, internal nodes numbered in that order
+        const SubNode* s = A.sub + n.sub;
+        const int base = nBfs + subBase[o];
+        int local[127];
+        int k = 0;
+        for (int j = 0; j < n.size; j++) local[j] = s[j].count > 0 ? -1 : k++;
+        for (int j = 0; j < n.size; j++) {
+            if (s[j].count > 0) { leafEnd[s[j].first + s[j].count - 1] = 1; continue; }
+            const SubNode &Lc = s[s[j].left], &Rc = s[s[j].right];
+            pt::PNode p;
+            for (int q = 0; q < 3; q++) { p.lmin[q] = Lc.lo[q]; p.lmax[q] = Lc.hi[q]; p.rmin[q] = Rc.lo[q]; p.rmax[q] = Rc.hi[q]; }
+            p.left = Lc.count > 0 ? ~Lc.first : base + local[s[j].left];
+            p.right = Rc.count > 0 ? ~Rc.first : base + local[s[j].right];
+            p.pad0 = p.pad1 = 0;
+            nodes[base + local[j]] = p;
+        }
+        return;
+    }
     if (n.count > 0) { leafEnd[n.first + n.count - 1] = 1; return; }
-    const OutNode &L = A.out[n.left], &R = A.out[n.right];
+    const OutNode &Lc = A.out[n.left], &Rc = A.out[n.right];
     pt::PNode p;
-    for (int k = 0; k < 3; k++) { p.lmin[k] = L.lo[k]; p.lmax[k] = L.hi[k]; p.rmin[k] = R.lo[k]; p.rmax[k] = R.hi[k]; }
-    p.left = L.count > 0 ? ~L.first : iid[n.left];
-    p.right = R.count > 0 ? ~R.first : iid[n.right];
+    for (int k = 0; k < 3; k++) { p.lmin[k] = Lc.lo[k]; p.lmax[k] = Lc.hi[k]; p.rmin[k] = Rc.lo[k]; p.rmax[k] = Rc.hi[k]; }
+    p.left = pack_ref(A, n.left, iid, subBase, nBfs);
+    p.right = pack_ref(A, n.right, iid, subBase, nBfs);
     p.pad0 = p.pad1 = 0;
     nodes[iid[o]] = p;
 }
@@ -745,7 +949,7 @@ struct Built {                        // what build_core leaves on the device (p
     void* pool = nullptr;
     Arrays A{};
     int* idx = nullptr;               // the final BVHindices permutation
-    int total = 0, levels = 0;
+    int total = 0, outTotal = 0, levels = 0, height = 0;   // reference nodes, breadth-first records, levels built level by level, tree height
     Ctl ctl{};
     hipEvent_t ev0 = nullptr;
     char* extra = nullptr;            // caller's scratch inside the pool
@@ -817,14 +1021,16 @@ int build_core(const pt_float4* positions, int n_positions, const pt_triangle* t
         const int gB = blocks(std::min<long long>(bound, n));
         hipLaunchKernelGGL(k_next_level, dim3(1), dim3(1), 0, st, A);
         hipLaunchKernelGGL(k_classify, dim3(gB), dim3(kBlock), 0, st, A, work, max_leaf_size);
+        if (kSmallNode > 0) hipLaunchKernelGGL(k_subtree, dim3(blocks(std::min<long long>(bound, n), kBlock / 64)), dim3(kBlock), 0, st, A, work, idx, max_leaf_size);
         hipLaunchKernelGGL(k_bin, dim3(gChunk), dim3(kBlock), 0, st, A, work, idx, nodeOf, chunk);
         hipLaunchKernelGGL(k_sah, dim3(gB), dim3(kBlock), 0, st, A, work);
         BVH_HIP(hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         if (ctl.bad) {
             (void)hipFree(B.pool); B.pool = nullptr;
-            return pt_fail_(ctl.bad == 3 ? -4 : -1, ctl.bad == 1 ? "pt_bvh_build_device: a triangle's vertex index is out of range"
+            return pt_fail_(ctl.bad >= 3 ? -4 : -1, ctl.bad == 1 ? "pt_bvh_build_device: a triangle's vertex index is out of range"
                                           : ctl.bad == 2 ? "pt_bvh_build_device: non-finite vertex position (the reference's tree is undefined for it)"
+                                          : ctl.bad == 4 ? "pt_bvh_build_device: internal error in the small-subtree pass"
                                                          : "pt_bvh_build_device: internal error, partition chain did not advance");
         }
         const int W = ctl.curCount;
@@ -869,21 +1075,27 @@ int build_core(const pt_float4* positions, int n_positions, const pt_triangle* t
         bound = 2LL * W;
     }
     // after the last level both index buffers agree on every position (leaves copy, splits scatter)
-    const int total = ctl.outCount;
+    const int outTotal = ctl.outCount;                             // breadth-first records (a small subtree is ONE record)
     const int L = (int)levelOff.size() - 1;
     for (int l = L - 1; l >= 0; l--)
         if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_size, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
     BVH_HIP(hipMemsetAsync(&A.out[0].pre, 0, sizeof(int), st));
     for (int l = 0; l < L; l++)
         if (levelOff[l + 1] > levelOff[l]) hipLaunchKernelGGL(k_pre, dim3(blocks(levelOff[l + 1] - levelOff[l])), dim3(kBlock), 0, st, A, levelOff[l], levelOff[l + 1]);
-    hipLaunchKernelGGL(k_emit, dim3(blocks(total)), dim3(kBlock), 0, st, A, total);
+    hipLaunchKernelGGL(k_emit, dim3(blocks(outTotal)), dim3(kBlock), 0, st, A, outTotal);
+    OutNode rootRec{};
+    BVH_HIP(hipMemcpyAsync(&rootRec, A.out, sizeof(OutNode), hipMemcpyDeviceToHost, st));
+    BVH_HIP(hipMemcpyAsync(&ctl, A.ctl, sizeof(ctl), hipMemcpyDeviceToHost, st));     // counters the subtree pass added to
+    BVH_HIP(hipStreamSynchronize(st));
+    const int total = rootRec.size;
+    B.outTotal = outTotal; B.height = rootRec.height;
     B.idx = idx; B.total = total; B.levels = levels;
     return 0;
 }
 
 void fill_stats(pt_bvh_build_stats* stats, const Built& B, float ms, std::chrono::steady_clock::time_point wall0) {
     if (!stats) return;
-    stats->n_nodes = B.total; stats->largest_leaf = B.ctl.largestLeaf; stats->backups = B.ctl.backups; stats->depth = B.levels;
+    stats->n_nodes = B.total; stats->largest_leaf = B.ctl.largestLeaf; stats->backups = B.ctl.backups; stats->depth = B.height;
     stats->sort_fallbacks = B.ctl.sortFallbacks; stats->levels = B.levels; stats->device_ms = ms;
     stats->total_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 }
@@ -925,7 +1137,8 @@ extern "C" int pt_bvh_build_pack_(const pt_scene_desc* d, const int* mat_types, 
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t offUvs = al(szNormals), offTypes = offUvs + al(szUvs), offLeafEnd = offTypes + al(szTypes);
     const size_t offF = offLeafEnd + al((size_t)n + 16), offS = offF + al(2 * (size_t)n + 16), offBlk = offS + al(sizeof(int) * (2 * (size_t)n + 2));
-    const size_t offFlags = offBlk + al(sizeof(int) * ((size_t)blocks(2LL * n, kScanTile) + 2)), extraBytes = offFlags + 256;
+    const size_t offS2 = offBlk + al(sizeof(int) * ((size_t)blocks(2LL * n, kScanTile) + 2));
+    const size_t offFlags = offS2 + al(sizeof(int) * (2 * (size_t)n + 2)), extraBytes = offFlags + 256;
     Built B;
     if (int r = build_core(d->positions, d->n_positions, d->triangles, n, max_leaf_size, extraBytes, B)) return r;
     char* X = B.extra;
@@ -937,26 +1150,39 @@ extern "C" int pt_bvh_build_pack_(const pt_scene_desc* d, const int* mat_types, 
     PackIn in{(const pt_float4*)X, d->n_normals, (const pt_float2*)(X + offUvs), d->n_uvs, (const int*)(X + offTypes), d->n_materials, d->n_lights};
     unsigned char* leafEnd = (unsigned char*)(X + offLeafEnd);
     int* flags = (int*)(X + offFlags);
-    // internal nodes in breadth-first order: exclusive scan of "is internal" over the builder's records
+    // internal nodes of the breadth-first part in that order (exclusive scan of "is internal" over the builder's
+    // records), then the subtrees' internal nodes (exclusive scan of their counts)
+    const int T = B.outTotal;
     Arrays S = B.A;                                      // the scan kernels read F / S / blockSum / n from their Arrays
-    S.F = (unsigned char*)(X + offF); S.S = (int*)(X + offS); S.blockSum = (int*)(X + offBlk); S.n = B.total;
+    S.F = (unsigned char*)(X + offF); S.S = (int*)(X + offS); S.blockSum = (int*)(X + offBlk); S.n = T;
+    Arrays S2 = S;
+    S2.S = (int*)(X + offS2);
     hipStream_t st = nullptr;
-    const int gT = blocks(B.total), gScan = blocks(B.total, kScanTile);
-    hipLaunchKernelGGL(k_pack_flags, dim3(gT), dim3(kBlock), 0, st, B.A, B.total, S.F);
+    const int gT = blocks(T), gScan = blocks(T, kScanTile);
+    hipLaunchKernelGGL(k_pack_flags, dim3(gT), dim3(kBlock), 0, st, B.A, T, S.F, 0);
     hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, S, 0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, S, gScan, 0);
     hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, S, 0);
-    hipLaunchKernelGGL(k_pack_nodes, dim3(gT), dim3(kBlock), 0, st, B.A, B.total, S.S, (pt::PNode*)d_nodes, leafEnd);
+    hipLaunchKernelGGL(k_pack_flags, dim3(gT), dim3(kBlock), 0, st, B.A, T, S.F, 1);
+    hipLaunchKernelGGL(k_scan1, dim3(gScan), dim3(kBlock), 0, st, S2, 0);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kBlock), 0, st, S2, gScan, 0);
+    hipLaunchKernelGGL(k_scan3, dim3(gScan), dim3(kBlock), 0, st, S2, 0);
+    hipLaunchKernelGGL(k_pack_nodes, dim3(gT), dim3(kBlock), 0, st, B.A, T, S.S, S2.S, (pt::PNode*)d_nodes, leafEnd);
     hipLaunchKernelGGL(k_pack_tris, dim3(blocks(n)), dim3(kBlock), 0, st, B.A, B.idx, in, leafEnd, (pt::PTri*)d_tris, flags);
     hipLaunchKernelGGL(k_pack_attrs, dim3(blocks(n)), dim3(kBlock), 0, st, B.A, in, (pt::PAttr*)d_attrs, flags);
     hipEvent_t ev1 = nullptr;
     BVH_HIP(hipEventCreate(&ev1));
     BVH_HIP(hipEventRecord(ev1, st));
-    int nInternal = 0, fl = 0;
+    int nBfs = 0, nSub = 0, fl = 0;
     OutNode rootRec{};
-    BVH_HIP(hipMemcpy(&nInternal, S.S + B.total, sizeof(int), hipMemcpyDeviceToHost));
+    SubNode rootSub{};
+    BVH_HIP(hipMemcpy(&nBfs, S.S + T, sizeof(int), hipMemcpyDeviceToHost));
+    BVH_HIP(hipMemcpy(&nSub, S2.S + T, sizeof(int), hipMemcpyDeviceToHost));
     BVH_HIP(hipMemcpy(&fl, flags, sizeof(int), hipMemcpyDeviceToHost));
     BVH_HIP(hipMemcpy(&rootRec, B.A.out, sizeof(OutNode), hipMemcpyDeviceToHost));
+    if (rootRec.sub >= 0) BVH_HIP(hipMemcpy(&rootSub, B.A.sub + rootRec.sub, sizeof(SubNode), hipMemcpyDeviceToHost));
+    const int nInternal = nBfs + nSub;
+    const int rootRef = rootRec.sub >= 0 ? (rootSub.count > 0 ? ~rootSub.first : nBfs) : (rootRec.count > 0 ? ~rootRec.first : 0);
     float ms = 0.0f;
     BVH_HIP(hipEventElapsedTime(&ms, B.ev0, ev1));
     (void)hipEventDestroy(B.ev0); (void)hipEventDestroy(ev1);
@@ -964,7 +1190,7 @@ extern "C" int pt_bvh_build_pack_(const pt_scene_desc* d, const int* mat_types, 
     if (fl & 1) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's material index is out of range");
     if (fl & 2) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's normal index is out of range (faces without vn must be given a normal by the loader)");
     if (fl & 4) return pt_fail_(-1, "pt_scene_create_from_mesh: a triangle's uv index is out of range");
-    out5[0] = nInternal; out5[1] = B.levels - 1; out5[2] = rootRec.count > 0 ? ~rootRec.first : 0; out5[3] = (fl & 0x100) ? 1 : 0; out5[4] = B.total;
+    out5[0] = nInternal; out5[1] = B.height - 1; out5[2] = rootRef; out5[3] = (fl & 0x100) ? 1 : 0; out5[4] = B.total;
     fill_stats(stats, B, ms, wall0);
     return 0;
 }

@@ -120,8 +120,12 @@ def _walk(nodes, ref, out):
     """Canonical depth-first listing of a packed tree: PNode numbering is any breadth-first order, the tree is not."""
     stack = [ref]
     f = nodes.view(np.float32).reshape(-1, 16); i = nodes.view(np.int32).reshape(-1, 16)
+    budget = 4 * len(nodes) + 8
     while stack:
+        budget -= 1
+        assert budget >= 0, "packed nodes do not form a tree"
         r = stack.pop()
+        assert r < len(nodes), "child reference out of range"
         if r < 0:
             out.append(("leaf", int(~r)))
             continue
