@@ -375,9 +375,18 @@ class Scene:
         _check(lib().pt_reset_counters(self.h), "pt_reset_counters")
 
     def debug_stamps(self):
-        out = np.zeros(6, np.uint64)
+        out = np.zeros(8, np.uint64)
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
-        return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end"), (int(v) for v in out)))
+        return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end", "slot6", "slot7"), (int(v) for v in out)))
+
+    def debug_lane_util(self):
+        """-DPT_UTIL builds, after a counting render: lanes carried per trip through the traversal loops."""
+        out = np.zeros(8, np.uint64)
+        _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
+        v = [int(x) for x in out]
+        names = ("closest_nodes", "closest_tris", "shadow_nodes", "shadow_tris")
+        return {n: {"wave_trips": v[2 * k], "lane_trips": v[2 * k + 1], "lanes_per_trip": (v[2 * k + 1] / v[2 * k]) if v[2 * k] else 0.0}
+                for k, n in enumerate(names)}
 
     def set_culling(self, on=True):
         """pt_set_culling: opt-in box culling (not the reference's visiting set; see pt_api.h)."""

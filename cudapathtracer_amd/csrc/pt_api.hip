@@ -65,6 +65,8 @@ struct pt_scene {
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
+    int nodeKeep = 0;                     // PT_NODE_KEEP
+    int refill = 0, refillKeep = 8;       // PT_REFILL / PT_REFILL_KEEP: REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / PT_CULL=1: opt-in, not parity-exact by construction
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
@@ -315,6 +317,9 @@ static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_
     if (const char* e = getenv("PT_WAVES_HBM")) { s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && e[0] == '2'; }
     if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
     if (const char* e = getenv("PT_CULL")) s->cull = (e[0] == '1');
+    if (const char* e = getenv("PT_NODE_KEEP")) s->nodeKeep = std::min(15, std::max(0, atoi(e)));
+    if (const char* e = getenv("PT_REFILL")) s->refill = atoi(e);
+    if (const char* e = getenv("PT_REFILL_KEEP")) s->refillKeep = std::min(15, std::max(0, atoi(e)));
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
     if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
     if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = atoi(e);     // 0 off, 1 once no fresh tile is left, 2 always
@@ -464,6 +469,9 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
+    P.refill = (s->refill && hbm && !P.cull && !s->armless) ? 1 : 0;
+    P.refillKeep = s->refillKeep;
+    P.nodeKeep = s->nodeKeep;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -609,10 +617,11 @@ int pt_reset_counters(pt_scene* s) {
     HIP_OK(hipMemset(s->totals.p, 0, 16 * sizeof(unsigned long long)));
     return 0;
 }
-// Diagnostic builds (-DPT_STAMPS) only: the six per-phase s_memtime sums; zeros otherwise.
-int pt_debug_stamps(pt_scene* s, unsigned long long* out6) {
-    if (!s || !out6) return fail(-1, "null argument");
-    HIP_OK(hipMemcpy(out6, (unsigned long long*)s->totals.p + 8, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+// Diagnostic builds only: the eight diagnostic sums behind the counters (-DPT_STAMPS: six per-phase s_memtime /
+// wall-clock sums; -DPT_UTIL: wave- and lane-level trip counts of the traversal loops); zeros otherwise.
+int pt_debug_stamps(pt_scene* s, unsigned long long* out8) {
+    if (!s || !out8) return fail(-1, "null argument");
+    HIP_OK(hipMemcpy(out8, (unsigned long long*)s->totals.p + 8, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

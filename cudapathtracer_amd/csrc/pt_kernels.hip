@@ -172,7 +172,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false>
 PT_DEV void megakernel_body(const KParams& P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
@@ -233,11 +233,13 @@ PT_DEV void megakernel_body(const KParams& P) {
                            __uint_as_float(state_load(o + 2, shared)), __uint_as_float(state_load(o + 3, shared)));
     }
     V3 acc = v3(acc4.x, acc4.y, acc4.z);
-    Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+    Ctr c = {};
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c); };
+    RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
+    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, P.nodeKeep); };
 
 #ifdef PT_STAMPS
     unsigned long long stamp[3] = {0, 0, 0};
@@ -292,6 +294,31 @@ PT_DEV void megakernel_body(const KParams& P) {
                 else __builtin_amdgcn_s_setprio(0);
             }
         }
+        if (REFILL) {
+            // Lanes whose rays are done take their logic step (DEFER form: the shadow ray is recorded, not traced
+            // inside the bounce) and start their next pair of rays; lanes still tracing skip it and resume below.
+            if (!(rs.flags & kRayBusy)) {
+                apply_pending(ps, thr, acc);
+                if (ps.flags & kInPath) {
+                    bool done = path_bounce<INTEG, COUNT, true>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+                    if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
+                    if (done) path_finish(ps, acc, true);
+                }
+                while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
+                    samplesLeft--;
+                    path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+                    if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, true);
+                }
+                const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
+                if (hasExt || hasShadow) ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+            }
+            PT_STAMP(2);
+            const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
+            if (nBusy == 0) break;
+            trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, P.nodeKeep);
+            PT_STAMP(1);
+            continue;
+        }
         if (DEFER) apply_pending(ps, thr, acc);
         if (ps.flags & kInPath) {
             bool done = path_bounce<INTEG, COUNT, DEFER>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
@@ -309,7 +336,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
-        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c);
+        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, P.nodeKeep);
         PT_STAMP(1);
     }
 
@@ -356,6 +383,9 @@ PT_DEV void megakernel_body(const KParams& P) {
             wave_add_total(P.totals, 2, c.pops); wave_add_total(P.totals, 3, c.boxes);
             wave_add_total(P.totals, 4, c.tris); wave_add_total(P.totals, 5, c.hits);
             wave_add_total(P.totals, 6, c.draws); wave_add_total(P.totals, 7, c.iters);
+#ifdef PT_UTIL
+            for (int k = 0; k < 8; k++) wave_add_total(P.totals, 8 + k, c.u[k]);     // in the slots of the PT_STAMPS diagnostic
+#endif
         }
     }
     }   // next tile
@@ -372,9 +402,9 @@ __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_M
 #endif
 megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds>(P); }
 
-template <int INTEG, bool COUNT, bool CULL>
+template <int INTEG, bool COUNT, bool CULL, bool REFILL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
-megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL>(P); }
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL>(P); }
 
 // -------------------------------------------------------------------------------------------
 // tile-major [local tile][64] <-> scan-line colors[y*w+x]
@@ -525,8 +555,9 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
     const bool hbm = P.wavesPerSimd == kWavesHbm;              // chosen by the host together with the spill layout
     const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : kStackLds);
 #define PT_LAUNCH_MK(I, C, D, O) hipLaunchKernelGGL((megakernel<I, C, D, O>), grid, block, lds, stream, P)
-#define PT_LAUNCH_HBM(I, C) do { if (P.cull) hipLaunchKernelGGL((megakernel_hbm<I, C, true>), grid, block, lds, stream, P); \
-                                 else hipLaunchKernelGGL((megakernel_hbm<I, C, false>), grid, block, lds, stream, P); } while (0)
+#define PT_LAUNCH_HBM(I, C) do { if (P.cull) hipLaunchKernelGGL((megakernel_hbm<I, C, true, false>), grid, block, lds, stream, P); \
+                                 else if (P.refill) hipLaunchKernelGGL((megakernel_hbm<I, C, false, true>), grid, block, lds, stream, P); \
+                                 else hipLaunchKernelGGL((megakernel_hbm<I, C, false, false>), grid, block, lds, stream, P); } while (0)
 #define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
                               else if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, true, false, false); } \
                               else { if (P.onchip) PT_LAUNCH_MK(I, false, false, true); else PT_LAUNCH_MK(I, false, false, false); } } while (0)

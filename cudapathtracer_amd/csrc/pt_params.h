@@ -31,6 +31,9 @@ struct KParams {
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
+    int nodeKeep;                  // a wave leaves its node loop once no more than active * nodeKeep / 16 lanes are still descending (pt_trace.h); 0 = when none is
+    int refill;                    // 1: the REFILL instantiation (pt_trace.h: trace_resume) — finished lanes shade and come back while the rest keep tracing
+    int refillKeep;                // the wave leaves the traversal when no more than busy * refillKeep / 16 lanes are still tracing
     int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)

@@ -23,7 +23,20 @@
 
 namespace pt {
 
-struct Ctr { uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters; };
+struct Ctr {
+    uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters;
+#ifdef PT_UTIL
+    uint32_t u[8];      // diagnostic build (tools/lane_util.py): {wave-level, lane-level} steps of the node / triangle loops, closest then shadow
+#endif
+};
+// Diagnostic build only (-DPT_UTIL, counting kernels): how many lanes does a trip through a traversal loop
+// carry? Every active lane counts itself (slot k+1), the first active lane counts the trip (slot k).
+#ifdef PT_UTIL
+#define PT_UTIL_STEP(c, k) do { if (COUNT) { (c).u[(k) + 1]++; const uint64_t e_ = __builtin_amdgcn_ballot_w64(true); \
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(e_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)e_, 0u)) == 0u) (c).u[k]++; } } while (0)
+#else
+#define PT_UTIL_STEP(c, k) do {} while (0)
+#endif
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 // Bit views of a float BY VALUE. (__builtin_bit_cast applied directly to an ext_vector element
@@ -151,7 +164,7 @@ PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V
 
 // BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
 template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
-PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
+PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nodeKeep = 0) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float min_t = 3.402823466e+38f;
     hit.tri = -1;
@@ -159,8 +172,14 @@ PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d,
     int32_t cur = S.rootRef;
     if (COUNT) c.raysClosest++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, min_t);
+        const int keep = (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) * nodeKeep) >> 4;
+        while (cur >= 0) {
+            PT_UTIL_STEP(c, 0);
+            cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, min_t);
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= keep) break;       // see node_loop_exit below
+        }
         if (cur == kRefNone) break;
+        if (cur >= 0) continue;
         if (COUNT) c.pops++;
         int32_t ti = ~cur;
         uint32_t idx;
@@ -168,6 +187,7 @@ PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d,
             TriData q = load_tri<ONCHIP>(S, C, ti);
             idx = f2u(q.e.y);
             if (COUNT) c.tris++;
+            PT_UTIL_STEP(c, 2);
             float t, u, v;
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < min_t) && (t < max_t)) {
@@ -192,15 +212,21 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 // BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
 template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
-PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
+PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, int nodeKeep = 0) {
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 thr = v3(1.0f);
     st.sp = 0;
     int32_t cur = S.rootRef;
     if (COUNT) c.raysShadow++;
     while (true) {
-        while (cur >= 0) cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, max_t);
+        const int keep = (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) * nodeKeep) >> 4;
+        while (cur >= 0) {
+            PT_UTIL_STEP(c, 4);
+            cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, max_t);
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= keep) break;
+        }
         if (cur == kRefNone) break;
+        if (cur >= 0) continue;
         if (COUNT) c.pops++;
         int32_t ti = ~cur;
         uint32_t idx;
@@ -208,6 +234,7 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
             TriData q = load_tri<ONCHIP>(S, C, ti);
             idx = f2u(q.e.y);
             if (COUNT) c.tris++;
+            PT_UTIL_STEP(c, 6);
             float t, u, v;
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < max_t)) {
@@ -367,6 +394,106 @@ PT_DEV void trace_pair(const DeviceScene& S, const SceneCache& C, Stack<N>& st, 
         cur = (!occluded && st.sp > 0) ? st.pop() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
     }
     if (COUNT) { if (hasExt && h.tri >= 0) c.hits++; }
+}
+
+// ---- resumable pair traversal (REFILL kernels) ------------------------------------------------
+// trace_pair leaves a wave in its loops until its LAST lane has finished; without culling the rays of
+// one wave differ widely in length, and on the 263 k-triangle scene a trip through the node loop carries 8.6 of
+// 64 lanes on average (tools/lane_util.py). Here the traversal state of a lane lives in a RayState that
+// survives the call: the wave leaves the loops as soon as no more than `minBusy` lanes are still tracing,
+// the lanes that finished run their logic step (shade, next-event record, regenerate) and come back with new
+// rays while the others simply continue where they stopped. Per ray the visiting order, the tests and the
+// counters are those of trace_closest / trace_shadow.
+struct RayState {
+    V3 o, d, inv;
+    float max_t, min_t;
+    int32_t cur;
+    uint32_t flags;                    // kRayBusy | kRayShadow | kRayExtFollows
+};
+constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u;
+
+template <bool COUNT, int N>
+PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasShadow, V3 so, V3 sd, float smaxt,
+                      bool hasExt, V3 eo, V3 ed, V3& thr, Hit& h, Ctr& c) {
+    h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+    thr = v3(1.0f);
+    if (COUNT) { if (hasShadow) c.raysShadow++; if (hasExt) c.raysClosest++; }
+    r.o = hasShadow ? so : eo; r.d = hasShadow ? sd : ed;
+    r.inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    r.max_t = hasShadow ? smaxt : 999999.0f;
+    r.min_t = 3.402823466e+38f;
+    r.cur = S.rootRef;
+    r.flags = kRayBusy | (hasShadow ? kRayShadow : 0u) | ((hasShadow && hasExt) ? kRayExtFollows : 0u);
+    st.sp = 0;
+}
+
+// (eo, ed): the lane's extension ray, needed when its shadow ray ends inside this call.
+template <bool COUNT, int N, bool ONCHIP>
+PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
+                         V3& thr, Hit& h, Ctr& c, int nodeKeep = 0) {
+    if (!(r.flags & kRayBusy)) return;
+    V3 o = r.o, d = r.d, inv = r.inv;
+    float max_t = r.max_t, min_t = r.min_t;
+    int32_t cur = r.cur;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    while (true) {
+        // wave-level early exit: the lanes still here keep their state for the next call
+        const int active = __builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+        if (active <= minBusy) break;
+        const int keep = (active * nodeKeep) >> 4;
+        while (cur >= 0) {
+            cur = descend<COUNT, N, ONCHIP>(S, C, cur, o, inv, st, c);
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= keep) break;
+        }
+        if (cur >= 0) continue;
+        if (cur == kRefNone) {
+            if (isShadow && extFollows) {               // shadow ray done: start this lane's extension ray
+                isShadow = false; extFollows = false;
+                o = eo; d = ed; inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); max_t = 999999.0f;
+                cur = S.rootRef; st.sp = 0;
+                continue;
+            }
+            busy = false;
+            break;
+        }
+        if (COUNT) c.pops++;
+        int32_t ti = ~cur;
+        uint32_t idx;
+        bool occluded = false;
+        do {
+            TriData q = load_tri<ONCHIP>(S, C, ti);
+            idx = f2u(q.e.y);
+            if (COUNT) c.tris++;
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (isShadow) {
+                if (ok && (t < max_t)) {
+                    uint32_t flags = f2u(q.e.w);
+                    if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                    // MAT_LEAF (integratorUtilities.cuh:218-239)
+                    const PMat& m = S.mats[f2i(q.e.z)];
+                    const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                    float bz = 1.0f - u - v;
+                    V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                    float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                    float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                    V3 sc = ld3(m.albedo) * m.transmission * (1.0f - F);
+                    thr = thr * sc;
+                    if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); occluded = true; break; }
+                }
+            } else if (ok && (t < min_t) && (t < max_t)) {
+                min_t = t;
+                h.t = t; h.u = u; h.v = v;
+                h.tri = (int32_t)(idx & 0x7fffffffu);
+                h.material = f2i(q.e.z);
+            }
+            ti++;
+        } while (!(idx & 0x80000000u));
+        cur = (!occluded && st.sp > 0) ? st.template pop<ONCHIP>() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
+    }
+    r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur;
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
+    if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }
 
 }  // namespace pt

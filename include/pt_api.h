@@ -180,10 +180,12 @@ int pt_scene_flags(pt_scene* scene);
  * 4.6e9 rays, at 1.57x the speed. A renderer's trade-off, not the reference's image. Applies to the
  * kernel for scenes that do not fit the LDS cache; flag bit 4 of pt_scene_flags reports it. */
 int pt_set_culling(pt_scene* scene, int on);
-/* Diagnostic builds (-DPT_STAMPS) only: per-phase s_memtime sums of the megakernel since the last
- * pt_reset_counters: regen, closest traversal, shading before the shadow ray, shadow traversal,
- * shading after it, loop overhead. Zeros in a normal build. */
-int pt_debug_stamps(pt_scene* scene, unsigned long long* out6);
+/* Diagnostic builds only, eight sums since the last pt_reset_counters; zeros in a normal build.
+ * -DPT_STAMPS: s_memtime spent in regeneration, closest-hit traversal, bounce logic (incl. the shadow ray), then the
+ * sum of wave lifetimes, ~(earliest start) and the latest end on the 100 MHz wall clock, 0, 0 (tools/stamps.py).
+ * -DPT_UTIL (counting launches): {trips of a wave, trips summed over its lanes} through the node loop and the
+ * triangle loop of the closest-hit traversal, then of the shadow traversal (tools/lane_util.py). */
+int pt_debug_stamps(pt_scene* scene, unsigned long long* out8);
 
 /* ---- probes: single stages of the path on the GPU, for known-answer tests -------------- */
 int pt_probe_rng(uint64_t seed, int n, const uint32_t* subsequences, int n_draws, uint32_t* out_state6, uint32_t* out_u32, float* out_uniform);
