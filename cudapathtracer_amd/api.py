@@ -395,7 +395,7 @@ class Scene:
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32)}
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

@@ -65,9 +65,10 @@ struct pt_scene {
     int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
-    int nodeKeep = 0;                     // PT_NODE_KEEP
-    int refill = 0, refillKeep = 8;       // PT_REFILL / PT_REFILL_KEEP: REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
+    int nodeKeep = 8, triKeep = 8;        // PT_NODE_KEEP / PT_TRI_KEEP (pt_trace.h: LoopExit)
+    int refill = 1, refillKeep = 4;       // PT_REFILL / PT_REFILL_KEEP: REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / PT_CULL=1: opt-in, not parity-exact by construction
+    int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
     bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
@@ -318,6 +319,7 @@ static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_
     if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
     if (const char* e = getenv("PT_CULL")) s->cull = (e[0] == '1');
     if (const char* e = getenv("PT_NODE_KEEP")) s->nodeKeep = std::min(15, std::max(0, atoi(e)));
+    if (const char* e = getenv("PT_TRI_KEEP")) s->triKeep = std::min(15, std::max(0, atoi(e)));
     if (const char* e = getenv("PT_REFILL")) s->refill = atoi(e);
     if (const char* e = getenv("PT_REFILL_KEEP")) s->refillKeep = std::min(15, std::max(0, atoi(e)));
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
@@ -469,9 +471,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
-    P.refill = (s->refill && hbm && !P.cull && !s->armless) ? 1 : 0;
+    P.refill = (s->refill && !deferred && !P.cull && !s->armless && (!onchip || s->refill == 2)) ? 1 : 0;   // 2: also the LDS-resident kernel (A/B)
     P.refillKeep = s->refillKeep;
-    P.nodeKeep = s->nodeKeep;
+    P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
+    s->lastLaunchRefill = P.refill;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -647,7 +650,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

@@ -239,7 +239,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     V3 thr = v3(1.0f);
     RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
     rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, P.nodeKeep); };
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep}); };
 
 #ifdef PT_STAMPS
     unsigned long long stamp[3] = {0, 0, 0};
@@ -315,7 +315,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             PT_STAMP(2);
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
-            trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, P.nodeKeep);
+            trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
             PT_STAMP(1);
             continue;
         }
@@ -336,7 +336,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
-        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, P.nodeKeep);
+        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, Keep{P.nodeKeep, P.triKeep});
         PT_STAMP(1);
     }
 
@@ -395,12 +395,12 @@ PT_DEV void megakernel_body(const KParams& P) {
 // 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
 // cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
 // included (5: +10 %, 7-8: no better). Both run the same body.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false>
 __global__ void __launch_bounds__(256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
 #endif
-megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds>(P); }
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL>(P); }
 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
@@ -558,7 +558,10 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
 #define PT_LAUNCH_HBM(I, C) do { if (P.cull) hipLaunchKernelGGL((megakernel_hbm<I, C, true, false>), grid, block, lds, stream, P); \
                                  else if (P.refill) hipLaunchKernelGGL((megakernel_hbm<I, C, false, true>), grid, block, lds, stream, P); \
                                  else hipLaunchKernelGGL((megakernel_hbm<I, C, false, false>), grid, block, lds, stream, P); } while (0)
+#define PT_LAUNCH_RF(I, C) do { if (P.onchip) hipLaunchKernelGGL((megakernel<I, C, false, true, true>), grid, block, lds, stream, P); \
+                                else hipLaunchKernelGGL((megakernel<I, C, false, false, true>), grid, block, lds, stream, P); } while (0)
 #define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
+                              else if (P.refill) { if (count) PT_LAUNCH_RF(I, true); else PT_LAUNCH_RF(I, false); } \
                               else if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, true, false, false); } \
                               else { if (P.onchip) PT_LAUNCH_MK(I, false, false, true); else PT_LAUNCH_MK(I, false, false, false); } } while (0)
     if (integrator == 2) PT_LAUNCH_MK2(2);

@@ -31,6 +31,7 @@ struct KParams {
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
+    int triKeep;                   // ... and its triangle loop once no more than entered * triKeep / 16 lanes still have triangles in their leaf
     int nodeKeep;                  // a wave leaves its node loop once no more than active * nodeKeep / 16 lanes are still descending (pt_trace.h); 0 = when none is
     int refill;                    // 1: the REFILL instantiation (pt_trace.h: trace_resume) — finished lanes shade and come back while the rest keep tracing
     int refillKeep;                // the wave leaves the traversal when no more than busy * refillKeep / 16 lanes are still tracing

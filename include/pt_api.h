@@ -171,7 +171,9 @@ int pt_reset_counters(pt_scene* scene);
  * on the launch stream around that kernel alone; waits for the launch to finish. */
 float pt_last_kernel_ms(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
- * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM (as used by the last launch; it needs enough tiles). For labelling measurements. */
+ * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
+ * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
+ * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a

@@ -194,6 +194,36 @@ def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
         sc.close()
 
 
+@pytest.mark.parametrize("knobs", [("0", "4", "0", "0", "2", "0", "512"),      # everything off: a wave stays in each loop until its last lane
+                                   ("0", "4", "15", "15", "2", "0", "4"),     # loops left as soon as ONE lane is through, shadow rays traced in the bounce
+                                   ("1", "1", "8", "8", "2", "0", "4"),       # production shape, traversal left only for the last sixteenth
+                                   ("1", "15", "15", "1", "0", "0", "8"),     # 4-wave kernel; traversal and node loop left at the first finished lane
+                                   ("1", "4", "1", "15", "2", "0", "0"),      # no time slices
+                                   ("2", "4", "8", "8", "1", "1", "4")])      # REFILL also for the LDS-resident instantiation (A/B only)
+def test_loop_exits_and_refill(api, gpu_ready, monkeypatch, knobs):
+    """pt_trace.h LoopExit / trace_resume: when a wave leaves its node loop, its triangle loop or the traversal
+    (lanes that are through go on, the others resume later) is scheduling, not arithmetic — golden colours AND the
+    per-pixel work counters bit for bit at every threshold, on all kernels (timed and counting instantiations)."""
+    for k, v in zip(("PT_REFILL", "PT_REFILL_KEEP", "PT_NODE_KEEP", "PT_TRI_KEEP", "PT_WAVES_HBM", "PT_ONCHIP", "PT_SLICE_ITERS"), knobs):
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PT_SCHED_MASK", "3")
+    used = []
+    for case in CASES:
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        sc = api.Scene(hs)
+        w, h = int(g["w"]), int(g["h"])
+        col, _ = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]))
+        assert_bits_equal(col, g["colors"], case)
+        used.append(sc.flags()["refill"])
+        col, cnt = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]), counters=True)
+        assert np.array_equal(cnt, g["counters"]), case
+        assert_bits_equal(col, g["colors"], case)
+        assert sc.last_kernel_ms() > 0.0
+        sc.close()
+    assert any(used) == (knobs[0] != "0"), used             # the REFILL instantiation really ran (or really did not)
+
+
 @pytest.mark.parametrize("integrator", [0, 2])
 def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integrator):
     from cudapathtracer_amd import scenes
