@@ -394,6 +394,7 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
     if (s->armless) return fail(-3, "the wavefront variant needs every material to have a dispatch arm (pt_path.h); use the megakernel");
     WfParams W;
     W.n = t.count * 64; W.w = w; W.h = h; W.tileFirst = t.first; W.tileStride = t.stride; W.tilesX = t.tilesX;
+    W.nodeKeep = s->nodeKeep; W.triKeep = s->triKeep;
     if (int r = s->wfState.ensure(wf_state_bytes(W.n))) return r;
     if (int r = s->wfCtl.ensure(64)) return r;
     wf_carve(W, s->wfState.p);

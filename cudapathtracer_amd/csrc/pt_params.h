@@ -86,6 +86,7 @@ struct WfParams {
     uint32_t* rng;       // [tile][6][64] as the megakernel
     float4* out;         // [tile][64] tile buffer
     int n, w, h, tileFirst, tileStride, tilesX;
+    int nodeKeep, triKeep;   // loop exits of the trace kernel (pt_trace.h: LoopExit), as KParams
 };
 size_t wf_state_bytes(int n);
 void wf_carve(WfParams& W, void* base);

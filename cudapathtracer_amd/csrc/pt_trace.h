@@ -328,12 +328,21 @@ struct Trav {
 
     // Descend to the next leaf and test its triangles. Returns true when the ray is finished.
     template <bool COUNT>
-    PT_DEV bool step(const DeviceScene& S, const SceneCache& C, Stack<N>& st, Ctr& c) {
-        while (cur >= 0) cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+    PT_DEV bool step(const DeviceScene& S, const SceneCache& C, Stack<N>& st, Ctr& c, Keep k = Keep{0, 0}) {
+        typedef LoopExit<false> X;
+        int keepN = 0;
+        if (X::node) keepN = (lanes_here() * k.node) >> 4;
+        while (cur >= 0) {
+            cur = descend<COUNT, N>(S, C, cur, o, inv, st, c);
+            if (X::node && lanes_here() <= keepN) break;
+        }
+        if (X::node && cur >= 0) return false;          // still descending: next call
         if (cur == kRefNone) return true;
-        if (COUNT) c.pops++;
         int32_t ti = ~cur;
         uint32_t idx;
+        int keepT = 0;
+        if (X::tri) keepT = (lanes_here() * k.tri) >> 4;
+        bool more;
         do {
             TriData q = load_tri(S, C, ti);
             idx = f2u(q.e.y);
@@ -343,7 +352,7 @@ struct Trav {
             if (shadow) {
                 if (ok && (t < max_t)) {
                     uint32_t flags = f2u(q.e.w);
-                    if (!(flags & 1u)) { thr = v3(0.0f); cur = kRefNone; return true; }
+                    if (!(flags & 1u)) { if (COUNT) c.pops++; thr = v3(0.0f); cur = kRefNone; return true; }
                     // MAT_LEAF (integratorUtilities.cuh:218-239)
                     const PMat& m = S.mats[f2i(q.e.z)];
                     const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -353,7 +362,7 @@ struct Trav {
                     float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
                     V3 sc = ld3(m.albedo) * m.transmission * (1.0f - F);
                     thr = thr * sc;
-                    if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); cur = kRefNone; return true; }
+                    if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { if (COUNT) c.pops++; thr = v3(0.0f); cur = kRefNone; return true; }
                 }
             } else if (ok && (t < min_t) && (t < max_t)) {
                 min_t = t;
@@ -362,7 +371,10 @@ struct Trav {
                 hit.material = f2i(q.e.z);
             }
             ti++;
-        } while (!(idx & 0x80000000u));
+            more = !(idx & 0x80000000u);
+        } while (more && !(X::tri && lanes_here() <= keepT));
+        if (X::tri && more) { cur = ~ti; return false; }       // the rest of this leaf next call
+        if (COUNT) c.pops++;
         cur = st.sp > 0 ? st.pop() : kRefNone;
         return cur == kRefNone;
     }

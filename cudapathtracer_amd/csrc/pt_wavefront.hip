@@ -241,7 +241,7 @@ wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_
         }
         if (__ballot(active) == 0ull) { if (drained) break; else continue; }
         // ---- one traversal step (to and through the next leaf) for every lane that holds a ray ----
-        if (active && tr.template step<COUNT>(S, SC, st, c)) {
+        if (active && tr.template step<COUNT>(S, SC, st, c, Keep{W.nodeKeep, W.triKeep})) {
             float* R = W.R + ray;
             if (tr.shadow) { R[R_THRX * 2 * n] = tr.thr.x; R[R_THRY * 2 * n] = tr.thr.y; R[R_THRZ * 2 * n] = tr.thr.z; }
             else {
