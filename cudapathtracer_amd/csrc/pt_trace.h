@@ -189,8 +189,43 @@ PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V
 }
 
 // BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
-template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
-PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, Keep k = Keep{0, 0}) {
+template <bool COUNT, int N, bool ONCHIP, bool CULL>
+PT_DEV void trace_closest_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float min_t = 3.402823466e+38f;
+    hit.tri = -1;
+    st.sp = 0;
+    int32_t cur = S.rootRef;
+    if (COUNT) c.raysClosest++;
+    while (true) {
+        while (cur >= 0) { PT_UTIL_STEP(c, 0); cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, min_t); }
+        if (cur == kRefNone) break;
+        if (COUNT) c.pops++;
+        int32_t ti = ~cur;
+        uint32_t idx;
+        do {
+            TriData q = load_tri<ONCHIP>(S, C, ti);
+            idx = f2u(q.e.y);
+            if (COUNT) c.tris++;
+            PT_UTIL_STEP(c, 2);
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (ok && (t < min_t) && (t < max_t)) {
+                min_t = t;
+                hit.t = t; hit.u = u; hit.v = v;
+                hit.tri = (int32_t)(idx & 0x7fffffffu);
+                hit.material = f2i(q.e.z);
+            }
+            ti++;
+        } while (!(idx & 0x80000000u));
+        cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
+    }
+    if (COUNT) { if (hit.tri >= 0) c.hits++; }
+}
+
+// ... and with the loop exits of LoopExit (same visits, same order, same counters).
+template <bool COUNT, int N, bool ONCHIP, bool CULL>
+PT_DEV void trace_closest_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, Keep k) {
     typedef LoopExit<ONCHIP> X;
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float min_t = 3.402823466e+38f;
@@ -228,12 +263,21 @@ PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d,
             }
             ti++;
             more = !(idx & 0x80000000u);
-        } while (more && !(X::tri && lanes_here() <= keepT));
+            if (X::tri && more && lanes_here() <= keepT) break;
+        } while (more);
         if (X::tri && more) { cur = ~ti; continue; }          // the rest of this leaf next time round
         if (COUNT) c.pops++;
         cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
     }
     if (COUNT) { if (hit.tri >= 0) c.hits++; }
+}
+
+template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
+PT_DEV void trace_closest(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, Keep k = Keep{0, 0}) {
+    // (two bodies rather than one with dead branches: the plain loops of the LDS-resident kernels are instruction-bound
+    // and the optimiser lays the merged form out differently, -2.7 % on Cornell)
+    if (LoopExit<ONCHIP>::node || LoopExit<ONCHIP>::tri) trace_closest_exits<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, hit, c, k);
+    else trace_closest_plain<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, hit, c);
 }
 
 PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // reflectors.cuh:183-188
@@ -244,8 +288,50 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 
 // BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
-template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
-PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k = Keep{0, 0}) {
+template <bool COUNT, int N, bool ONCHIP, bool CULL>
+PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 thr = v3(1.0f);
+    st.sp = 0;
+    int32_t cur = S.rootRef;
+    if (COUNT) c.raysShadow++;
+    while (true) {
+        while (cur >= 0) { PT_UTIL_STEP(c, 4); cur = descend<COUNT, N, ONCHIP, CULL>(S, C, cur, o, inv, st, c, max_t); }
+        if (cur == kRefNone) break;
+        if (COUNT) c.pops++;
+        int32_t ti = ~cur;
+        uint32_t idx;
+        do {
+            TriData q = load_tri<ONCHIP>(S, C, ti);
+            idx = f2u(q.e.y);
+            if (COUNT) c.tris++;
+            PT_UTIL_STEP(c, 6);
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (ok && (t < max_t)) {
+                uint32_t flags = f2u(q.e.w);
+                if (!(flags & 1u)) return v3(0.0f);
+                // MAT_LEAF (integratorUtilities.cuh:218-239)
+                const PMat& m = S.mats[f2i(q.e.z)];
+                const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                float bz = 1.0f - u - v;
+                V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                V3 s = ld3(m.albedo) * m.transmission * (1.0f - F);
+                thr = thr * s;
+                if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) return v3(0.0f);
+            }
+            ti++;
+        } while (!(idx & 0x80000000u));
+        cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
+    }
+    return thr;
+}
+
+// ... and with the loop exits of LoopExit.
+template <bool COUNT, int N, bool ONCHIP, bool CULL>
+PT_DEV V3 trace_shadow_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k) {
     typedef LoopExit<ONCHIP> X;
     V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 thr = v3(1.0f);
@@ -290,12 +376,19 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
             }
             ti++;
             more = !(idx & 0x80000000u);
-        } while (more && !(X::tri && lanes_here() <= keepT));
+            if (X::tri && more && lanes_here() <= keepT) break;
+        } while (more);
         if (X::tri && more) { cur = ~ti; continue; }
         if (COUNT) c.pops++;
         cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
     }
     return thr;
+}
+
+template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
+PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k = Keep{0, 0}) {
+    if (LoopExit<ONCHIP>::node || LoopExit<ONCHIP>::tri) return trace_shadow_exits<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, c, k);
+    return trace_shadow_plain<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, c);
 }
 
 
@@ -372,7 +465,8 @@ struct Trav {
             }
             ti++;
             more = !(idx & 0x80000000u);
-        } while (more && !(X::tri && lanes_here() <= keepT));
+            if (X::tri && more && lanes_here() <= keepT) break;
+        } while (more);
         if (X::tri && more) { cur = ~ti; return false; }       // the rest of this leaf next call
         if (COUNT) c.pops++;
         cur = st.sp > 0 ? st.pop() : kRefNone;
@@ -545,7 +639,8 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
             }
             ti++;
             more = !(idx & 0x80000000u);
-        } while (more && !(X::tri && lanes_here() <= keepT));
+            if (X::tri && more && lanes_here() <= keepT) break;
+        } while (more);
         if (X::tri && !occluded && more) { cur = ~ti; continue; }                 // the rest of this leaf next time round
         if (COUNT) c.pops++;
         cur = (!occluded && st.sp > 0) ? st.template pop<ONCHIP>() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
