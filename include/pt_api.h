@@ -179,7 +179,7 @@ int pt_scene_flags(pt_scene* scene);
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a
  * triangle inside a skipped box can still produce a smaller t (different roundings, grazing incidence), and one such
  * hit shifts the pixel's whole RNG stream. Measured on the 263 k-triangle scene: 13 of 2 073 600 pixels differ after
- * 4.6e9 rays, at 1.57x the speed. A renderer's trade-off, not the reference's image. Applies to the
+ * 4.6e9 rays, at 1.2-1.6x the speed. A renderer's trade-off, not the reference's image. Applies to the
  * kernel for scenes that do not fit the LDS cache; flag bit 4 of pt_scene_flags reports it. */
 int pt_set_culling(pt_scene* scene, int on);
 /* Diagnostic builds only, eight sums since the last pt_reset_counters; zeros in a normal build.
