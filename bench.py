@@ -82,9 +82,9 @@ def pmc_traffic(workload, spp):
     """HBM bytes per megakernel launch from the committed rocprofv3 PMC passes (profiles/), if they
     were taken on this workload; None otherwise. bench.py cannot run the profiler on itself."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if t.get("workload") == workload and t.get("spp") == spp:
-            return t["hbm_bytes_per_launch"]
+        for t in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:
+            if t.get("workload") == workload and t.get("spp") == spp:
+                return t["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return None
