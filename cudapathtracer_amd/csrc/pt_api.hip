@@ -456,9 +456,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     // 176 vs 185 ms, 1/4 shard equal, 1/2 shard 602 vs 518 ms on the 263 k-triangle scene).
     const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * kWavesHbm * 5);
     const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
-    int blocks = megakernel_blocks(t.count);
+    const int wgWaves = hbm ? kWgWavesHbm : 4;
+    int blocks = megakernel_blocks(t.count, wgWaves);
     if (spillEntries > 0)
-        if (int r = s->spill.ensure((size_t)blocks * 4 * spillEntries * 64 * sizeof(int32_t))) return r;
+        if (int r = s->spill.ensure((size_t)blocks * wgWaves * spillEntries * 64 * sizeof(int32_t))) return r;
     // continueStreams: a later chunk of a progressive render keeps the per-pixel XORWOW states the
     // previous chunk stored (the reference reloads / stores them around every sample, deviceCode.cu:294, 541)
     if (!continueStreams) HIP_OK(launch_rng_init((const uint32_t*)s->jump.p, seed, w, h, t, (uint32_t*)s->rng.p, stream));
@@ -469,6 +470,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
+    P.wgWaves = wgWaves;
+    if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, kCacheBytesHbm / 64);     // its workgroups share a larger copy of the top of the tree
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
@@ -487,7 +490,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         if (int r = s->queue.ensure((size_t)(8 + 2 * cap) * sizeof(int))) return r;
         if (int r = s->left.ensure((size_t)t.count * 64 * sizeof(int))) return r;
         P.queue = (int*)s->queue.p; P.queueMask = cap - 1; P.left = (int*)s->left.p;
-        P.gridBlocks = s->numCU * P.wavesPerSimd;      // n waves per SIMD = n 4-wave workgroups per CU
+        P.gridBlocks = s->numCU * P.wavesPerSimd * 4 / wgWaves;      // n waves per SIMD = 4n waves per CU, in workgroups of wgWaves
     }
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;

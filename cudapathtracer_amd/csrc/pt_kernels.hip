@@ -176,7 +176,7 @@ template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL 
 PT_DEV void megakernel_body(const KParams& P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     // Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2. Default: tile =
     // blockIdx order, i.e. the XCDs interleave over the frame at 32x8-pixel granularity — every XCD gets
     // the same mix of cheap and expensive regions. xcdBands (PT_XCD_BANDS=1) instead gives each XCD one
@@ -201,7 +201,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         lt = item & ~kFreshBit;
     } else {
         if (!first) break;
-        lt = vb * 4 + wave;
+        lt = vb * nW + wave;
     }
     if (lt >= P.tileCount) break;
     const int tile = P.tileFirst + lt * P.tileStride;
@@ -211,10 +211,10 @@ PT_DEV void megakernel_body(const KParams& P) {
     const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
     Stack<STACKN> st;
     st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (STACKN * 64) + lane;
-    st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * 4 + wave) * S.stackSpill) * 64 + lane : nullptr;
+    st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * nW + wave) * S.stackSpill) * 64 + lane : nullptr;
     st.sp = 0;
     LdsMedium ms;
-    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + 4 * STACKN * 256) + wave * (kMediumMax * 64) + lane;
+    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + nW * STACKN * 256) + wave * (kMediumMax * 64) + lane;
 
     PathState ps;
     const bool shared = P.queue != nullptr && !COUNT && P.sliceIters > 0;       // tiles may change hands
@@ -403,7 +403,7 @@ __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_M
 megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL>(P); }
 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
+__global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
 megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL>(P); }
 
 // -------------------------------------------------------------------------------------------
@@ -546,18 +546,20 @@ hipError_t launch_rng_init(const uint32_t* jump, unsigned long long seed, int w,
 
 hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const KParams& P, hipStream_t stream) {
     if (P.tileCount <= 0) return hipSuccess;
-    int nBlocks = megakernel_blocks(P.tileCount);
+    int nBlocks = megakernel_blocks(P.tileCount, P.wgWaves);
     if (P.queue && P.gridBlocks > 0) {
         nBlocks = std::min(nBlocks, P.gridBlocks);
         hipLaunchKernelGGL(queue_init_kernel, dim3((P.queueMask + 256) / 256), dim3(256), 0, stream, P.queue, P.queueMask, P.tileCount);
     }
-    dim3 grid(nBlocks), block(256);
+    dim3 grid(nBlocks), block(64 * P.wgWaves);
     const bool hbm = P.wavesPerSimd == kWavesHbm;              // chosen by the host together with the spill layout
-    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : kStackLds);
+    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : kStackLds, P.wgWaves);
+    // more than 64 KB of dynamic LDS per workgroup has to be asked for (a workgroup may take all 160 KB of its CU)
+#define PT_LDS_OK(K) do { if (lds > 65536u) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e_ != hipSuccess) return e_; } } while (0)
 #define PT_LAUNCH_MK(I, C, D, O) hipLaunchKernelGGL((megakernel<I, C, D, O>), grid, block, lds, stream, P)
-#define PT_LAUNCH_HBM(I, C) do { if (P.cull) hipLaunchKernelGGL((megakernel_hbm<I, C, true, false>), grid, block, lds, stream, P); \
-                                 else if (P.refill) hipLaunchKernelGGL((megakernel_hbm<I, C, false, true>), grid, block, lds, stream, P); \
-                                 else hipLaunchKernelGGL((megakernel_hbm<I, C, false, false>), grid, block, lds, stream, P); } while (0)
+#define PT_LAUNCH_HBM1(I, C, CU, RF) do { PT_LDS_OK((megakernel_hbm<I, C, CU, RF>)); hipLaunchKernelGGL((megakernel_hbm<I, C, CU, RF>), grid, block, lds, stream, P); } while (0)
+#define PT_LAUNCH_HBM(I, C) do { if (P.cull) PT_LAUNCH_HBM1(I, C, true, false); else if (P.refill) PT_LAUNCH_HBM1(I, C, false, true); \
+                                 else PT_LAUNCH_HBM1(I, C, false, false); } while (0)
 #define PT_LAUNCH_RF(I, C) do { if (P.onchip) hipLaunchKernelGGL((megakernel<I, C, false, true, true>), grid, block, lds, stream, P); \
                                 else hipLaunchKernelGGL((megakernel<I, C, false, false, true>), grid, block, lds, stream, P); } while (0)
 #define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \

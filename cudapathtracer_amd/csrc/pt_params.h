@@ -23,6 +23,16 @@ constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
 constexpr int kStackLdsHbm = 8;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
 constexpr int kCacheBytes = PT_CACHE_BYTES;
+// The kernel for scenes in HBM runs in workgroups of PT_WG_WAVES_HBM waves (default 12: two workgroups per CU at 6
+// waves per SIMD) so that its waves SHARE one large LDS copy of the top of the tree instead of six small ones:
+// 80 KB per workgroup - 12 x (2 KB stack + 1 KB medium stack) = 44 KB = the first 704 PNodes, which take 45 % of all
+// node visits on the 263 k-triangle scene (the first 192 of the 12 KB cache: 32 %). 4 = the old shape.
+#ifndef PT_WG_WAVES_HBM
+#define PT_WG_WAVES_HBM 12
+#endif
+constexpr int kWgWavesHbm = (PT_WAVES_HBM > 0 && (kWavesHbm * 4) % PT_WG_WAVES_HBM == 0 && PT_WG_WAVES_HBM <= 16) ? PT_WG_WAVES_HBM : 4;
+constexpr int kCacheBytesHbm = kWgWavesHbm == 4 ? kCacheBytes
+                                                : ((160 * 1024) / ((kWavesHbm * 4) / kWgWavesHbm) - kWgWavesHbm * (kStackLdsHbm * 256 + kMediumMax * 64)) / 64 * 64;
 
 struct KParams {
     DeviceScene S;
@@ -35,6 +45,7 @@ struct KParams {
     int nodeKeep;                  // a wave leaves its node loop once no more than active * nodeKeep / 16 lanes are still descending (pt_trace.h); 0 = when none is
     int refill;                    // 1: the REFILL instantiation (pt_trace.h: trace_resume) — finished lanes shade and come back while the rest keep tracing
     int refillKeep;                // the wave leaves the traversal when no more than busy * refillKeep / 16 lanes are still tracing
+    int wgWaves;                   // waves per workgroup of this launch (4, or kWgWavesHbm for megakernel_hbm)
     int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)
@@ -116,9 +127,9 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
                                   float* out4, hipStream_t stream);
 // waves a probe_closest/shadow launch of n rays uses (spill sizing)
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
-inline int megakernel_blocks(int tileCount) { return (tileCount + 3) / 4; }
-inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds) {
-    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)stackEntries * 256 + 4 * (size_t)kMediumMax * 64;
+inline int megakernel_blocks(int tileCount, int wgWaves = 4) { return (tileCount + wgWaves - 1) / wgWaves; }
+inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4) {
+    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (size_t)kMediumMax * 64);
 }
 
 }  // namespace pt

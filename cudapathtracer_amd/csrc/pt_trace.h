@@ -590,6 +590,9 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
         const int keepN = (active * k.node) >> 4;
         while (cur >= 0) {
             PT_UTIL_STEP(c, 0);
+#ifdef PT_UTIL_DEPTH
+            if (COUNT) { c.u[4] += cur < 192; c.u[5] += cur < 704; c.u[6] += cur < 1792; c.u[7] += cur < 8192; }
+#endif
             cur = descend<COUNT, N, ONCHIP>(S, C, cur, o, inv, st, c);
             if (X::node && lanes_here() <= keepN) break;
         }
