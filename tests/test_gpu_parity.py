@@ -238,10 +238,15 @@ def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integr
         assert_bits_equal(col, ocol, cfg)
 
 
+@pytest.mark.parametrize("layout", ["queue", "one_tile_per_wave", "xcd_bands"])
 @pytest.mark.parametrize("integrator", [0, 2])
-def test_render_hand_built_deep_tree(api, oracle, gpu_ready, monkeypatch, integrator):
-    """Array-level boundary + a tree deeper than the LDS stack, through the full render loop."""
+def test_render_hand_built_deep_tree(api, oracle, gpu_ready, monkeypatch, integrator, layout):
+    """Array-level boundary + a tree deeper than the LDS stack, through the full render loop — in the 12-wave
+    workgroups of the kernel for scenes in HBM (shared scene cache, per-wave spill areas), fed by the tile queue,
+    one tile per wave (PT_PERSISTENT=0) or in per-XCD bands."""
     monkeypatch.setenv("PT_WAVES_HBM", "2")              # the 6-wave kernel also for this 6-tile frame
+    if layout == "one_tile_per_wave": monkeypatch.setenv("PT_PERSISTENT", "0")
+    if layout == "xcd_bands": monkeypatch.setenv("PT_XCD_BANDS", "1")
     arr = _chain_arrays(api)
     gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
     cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
