@@ -206,7 +206,7 @@ def main():
                        "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, spp) if (world == 1 and args.variant == "megakernel") else None,
-                         "kernel": (("pt::megakernel_hbm<0, false, %s, %s>" % (_tf(scene.flags()["culling"]), _tf(scene.flags()["refill"]))) if scene.flags()["hbm_kernel"] else "pt::megakernel<0, false, false, %s, %s>" % (_tf(scene.flags()["onchip"]), _tf(scene.flags()["refill"]))) if args.variant == "megakernel" else "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
+                         "kernel": (("pt::megakernel_hbm<0, false, %s, %s>" % (_tf(scene.flags()["culling"]), _tf(scene.flags()["refill"]))) if scene.flags()["hbm_kernel"] else "pt::megakernel<0, false, false, %s, %s, %s>" % (_tf(scene.flags()["onchip"]), _tf(scene.flags()["refill"]), _tf(scene.flags()["flat"]))) if args.variant == "megakernel" else "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sinfo["config"], info)

@@ -337,7 +337,10 @@ class Scene:
         col = np.zeros((h, w, 4), np.float32) if out is None else out
         cnt = np.zeros((h, w, 8), np.uint32) if counters else None
         tr = C.byref(tiles) if tiles is not None else None
-        rc = lib().pt_render_counted(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, tr, _p(col), _p(cnt))
+        if counters:
+            rc = lib().pt_render_counted(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, tr, _p(col), _p(cnt))
+        else:                                               # the timed kernels (time slices, REFILL / FLAT instantiations)
+            rc = lib().pt_render(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, tr, _p(col))
         _check(rc, "pt_render")
         return col, cnt
 
@@ -377,7 +380,7 @@ class Scene:
     def debug_stamps(self):
         out = np.zeros(8, np.uint64)
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
-        return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end", "slot6", "slot7"), (int(v) for v in out)))
+        return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end", "shadow_in_bounce", "slot7"), (int(v) for v in out)))
 
     def debug_lane_util(self):
         """-DPT_UTIL builds, after a counting render: lanes carried per trip through the traversal loops."""
@@ -395,7 +398,7 @@ class Scene:
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64)}
 
     def last_kernel_ms(self):
         return float(lib().pt_last_kernel_ms(self.h))

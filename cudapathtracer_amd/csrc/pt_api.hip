@@ -68,6 +68,8 @@ struct pt_scene {
     int nodeKeep = 8, triKeep = 8;        // PT_NODE_KEEP / PT_TRI_KEEP (pt_trace.h: LoopExit)
     int refill = 1, refillKeep = 4;       // PT_REFILL / PT_REFILL_KEEP: REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / PT_CULL=1: opt-in, not parity-exact by construction
+    bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / PT_FLAT=0 turns them off (A/B)
+    int lastLaunchFlat = 0;
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
@@ -301,6 +303,42 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
     s->nTrisPacked = nT;
     if ((size_t)nInternal * 64 + (size_t)nT * 48 <= (size_t)kCacheBytes) { s->cacheNodes = nInternal; s->cacheTris = nT; }
     else { s->cacheNodes = std::min(nInternal, kCacheBytes / 64); s->cacheTris = 0; }
+    // FLAT kernels (pt_trace.h): one forward pass over the internal nodes with 64-bit masks — needs at most 64 of each,
+    // every child numbered after its parent (the breadth-first numbering gives that; checked on the packed records) and
+    // the triangle count of every leaf child, which goes into the spare words of its PNode.
+    s->flatOk = false;
+    if (nInternal <= 64 && nT >= 1 && nT <= 64 && s->cacheNodes == nInternal && s->cacheTris == nT) {
+        std::vector<PNode> pn((size_t)std::max(nInternal, 1));
+        std::vector<PTri> pt((size_t)nT);
+        if (nInternal > 0) HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nInternal * sizeof(PNode), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(pt.data(), s->tris.p, (size_t)nT * sizeof(PTri), hipMemcpyDeviceToHost));
+        auto leafCount = [&](int first) {                      // triangles up to and including the one flagged last
+            int k = first;
+            while (k < nT) { uint32_t w; memcpy(&w, (const char*)&pt[k] + 36, 4); k++; if (w & 0x80000000u) return k - first; }
+            return 0;                                          // runs off the end: not a well-formed leaf
+        };
+        bool ok = rootRef < 0 ? (~rootRef == 0 && leafCount(0) == nT) : (rootRef == 0);
+        std::vector<int> first((size_t)std::max(nInternal, 1), 0);   // first triangle below node i
+        for (int i = nInternal - 1; i >= 0 && ok; i--) {          // children come after their parent: bottom-up
+            int32_t* ref = &pn[i].left;                         // left, right, pad0, pad1
+            int firstOf[2] = {0, 0};
+            for (int k = 0; k < 2 && ok; k++) {
+                if (ref[k] >= 0) {
+                    ok = ref[k] > i && ref[k] < nInternal;
+                    if (ok) { ref[2 + k] = pn[ref[k]].pad0 + pn[ref[k]].pad1; firstOf[k] = first[ref[k]]; }
+                } else {
+                    const int f = ~ref[k]; const int cnt = (ref[k] != kRefNone && f < nT) ? leafCount(f) : 0;
+                    ok = cnt >= 1; ref[2 + k] = cnt; firstOf[k] = f;
+                }
+            }
+            // leaf order is left to right: the right subtree's triangles follow the left subtree's
+            ok = ok && firstOf[1] == firstOf[0] + ref[2];
+            first[i] = firstOf[0];
+        }
+        if (ok && nInternal > 0) ok = first[0] == 0 && pn[0].pad0 + pn[0].pad1 == nT;
+        if (ok && nInternal > 0) HIP_OK(hipMemcpy(s->nodes.p, pn.data(), (size_t)nInternal * sizeof(PNode), hipMemcpyHostToDevice));
+        s->flatOk = ok;
+    }
     return 0;
 }
 
@@ -320,6 +358,7 @@ static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_
     if (const char* e = getenv("PT_CULL")) s->cull = (e[0] == '1');
     if (const char* e = getenv("PT_NODE_KEEP")) s->nodeKeep = std::min(15, std::max(0, atoi(e)));
     if (const char* e = getenv("PT_TRI_KEEP")) s->triKeep = std::min(15, std::max(0, atoi(e)));
+    if (const char* e = getenv("PT_FLAT")) s->flatWanted = (e[0] != '0');
     if (const char* e = getenv("PT_REFILL")) s->refill = atoi(e);
     if (const char* e = getenv("PT_REFILL_KEEP")) s->refillKeep = std::min(15, std::max(0, atoi(e)));
     if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
@@ -478,7 +517,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.refill = (s->refill && !deferred && !P.cull && !s->armless && (!onchip || s->refill == 2)) ? 1 : 0;   // 2: also the LDS-resident kernel (A/B)
     P.refillKeep = s->refillKeep;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
-    s->lastLaunchRefill = P.refill;
+    P.flat = (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) ? 1 : 0;
+    s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -570,8 +610,8 @@ int pt_launch_naive_unidirectional(int maxDepth, pt_camera camera, pt_scene* sce
     return launch_on_colors(scene, &camera, w, h, numSample, maxDepth, PT_NAIVE_UNIDIRECTIONAL, useMIS, 103033ull, nullptr, d_colors, nullptr, false);
 }
 
-int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
-                      const pt_tile_range* tiles, float* out, uint32_t* outCounters) {
+static int render_host(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
+                       const pt_tile_range* tiles, float* out, uint32_t* outCounters, bool count) {
     if (!out) return fail(-1, "null output buffer");
     if (int r = check_render_args(s, cam, spp, integrator)) return r;
     TileSpan t;
@@ -584,7 +624,7 @@ int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, 
         if (int r = s->pixcnt.ensure(std::max<size_t>((size_t)t.count * 512 * sizeof(uint32_t), 16))) return r;
         dpc = (uint32_t*)s->pixcnt.p;
     }
-    if (int r = launch_on_colors(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, s->colors.p, dpc, true)) return r;
+    if (int r = launch_on_colors(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, s->colors.p, dpc, count)) return r;
     HIP_OK(hipMemcpy(out, s->colors.p, px * sizeof(float4), hipMemcpyDeviceToHost));
     if (int r = queue_error(s)) return r;
     if (outCounters) {
@@ -602,9 +642,15 @@ int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, 
     return 0;
 }
 
+// pt_render runs the kernels the bench times; pt_render_counted the counting instantiations (same image, per-pixel
+// and total work counters on the side, no time slices).
 int pt_render(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
               const pt_tile_range* tiles, float* out) {
-    return pt_render_counted(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, nullptr);
+    return render_host(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, nullptr, false);
+}
+int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS, uint64_t seed,
+                      const pt_tile_range* tiles, float* out, uint32_t* outCounters) {
+    return render_host(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, outCounters, true);
 }
 
 int pt_set_variant(pt_scene* s, int variant) {
@@ -654,7 +700,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

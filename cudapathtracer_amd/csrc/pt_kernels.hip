@@ -172,7 +172,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false>
 PT_DEV void megakernel_body(const KParams& P) {
     const DeviceScene& S = P.S;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris);      // contains the only barrier
@@ -239,13 +239,18 @@ PT_DEV void megakernel_body(const KParams& P) {
     V3 thr = v3(1.0f);
     RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
     rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
-    auto shadowSync = [&](V3 ro, V3 wi, float maxt) { return trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep}); };
-
 #ifdef PT_STAMPS
-    unsigned long long stamp[3] = {0, 0, 0};
+    unsigned long long stamp[4] = {0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long wall0 = wall_clock64();     // device-wide 100 MHz clock: slot occupancy (tools/stamps.py)
 #endif
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) {
+        PT_STAMP(2);
+        const V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+        PT_STAMP(3);
+        return t_;
+    };
+
     // Every iteration: one logic step per lane (finish the previous bounce's NEE, shade the hit,
     // regenerate if the path ended), then one traversal round for the rays the logic produced. A
     // lane whose path ended starts its pixel's next sample in the same step, so the wave keeps 64
@@ -336,6 +341,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+        else if constexpr (FLAT) trace_closest_flat<STACKN>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes);
         else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, Keep{P.nodeKeep, P.triKeep});
         PT_STAMP(1);
     }
@@ -347,6 +353,7 @@ PT_DEV void megakernel_body(const KParams& P) {
 #ifdef PT_STAMPS
     if (P.totals && lane == 0) {
         for (int k = 0; k < 3; k++) atomicAdd(&P.totals[8 + k], stamp[k]);   // regeneration, closest-hit traversal, bounce logic
+        atomicAdd(&P.totals[14], stamp[3]);                                    // shadow rays traced inside the bounce (SYNC kernels)
         const unsigned long long wall1 = wall_clock64();
         atomicAdd(&P.totals[11], wall1 - wall0);             // sum of wave lifetimes
         atomicMax(&P.totals[12], ~wall0);                     // ~(earliest start)
@@ -395,12 +402,12 @@ PT_DEV void megakernel_body(const KParams& P) {
 // 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
 // cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
 // included (5: +10 %, 7-8: no better). Both run the same body.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false>
 __global__ void __launch_bounds__(256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
 #endif
-megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL>(P); }
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT>(P); }
 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
@@ -564,6 +571,7 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
                                 else hipLaunchKernelGGL((megakernel<I, C, false, false, true>), grid, block, lds, stream, P); } while (0)
 #define PT_LAUNCH_MK2(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
                               else if (P.refill) { if (count) PT_LAUNCH_RF(I, true); else PT_LAUNCH_RF(I, false); } \
+                              else if (P.flat && !count) hipLaunchKernelGGL((megakernel<I, false, false, true, false, true>), grid, block, lds, stream, P); \
                               else if (count) { if (P.onchip) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, true, false, false); } \
                               else { if (P.onchip) PT_LAUNCH_MK(I, false, false, true); else PT_LAUNCH_MK(I, false, false, false); } } while (0)
     if (integrator == 2) PT_LAUNCH_MK2(2);

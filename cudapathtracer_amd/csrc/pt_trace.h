@@ -392,6 +392,170 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
 }
 
 
+// ---- FLAT closest hit: tiny LDS-resident scenes (at most 64 internal nodes and 64 packed triangles) ----
+// Without culling the set of leaves a ray visits does not depend on what it hits: a leaf is visited iff slab() passes
+// for every box on the way down. The stack walk of a Cornell-class scene spends its time diverged (a trip through
+// the node loop carries 24 of 64 lanes, through the triangle loop 16, tools/lane_util.py). Here the wave works as one:
+//   1. it walks ALL internal nodes in index order (breadth-first numbering: parents first) in lockstep; each lane
+//      keeps a 64-bit "visited" mask and collects the triangles of the leaves it visits in a 64-bit mask — the
+//      same slab() on the same operands, gated exactly as the reference's descent;
+//   2. the (ray, triangle) tests of the whole wave — the set bits of all 64 masks — are dealt out evenly: test p
+//      goes to lane p mod 64, which looks up the owning ray (prefix sums, in LDS), runs the same Moller-Trumbore
+//      on that ray and folds (t, triangle) into the ray's minimum with an LDS atomic;
+//   3. every ray's owner re-runs the test on the winner for (t, u, v) — the same arithmetic, so the same bits.
+// What this does not know is the reference's visiting ORDER, which decides between two triangles that return the
+// same t (strict `t < min_t`: the first one visited wins); step 3 reconstructs that decision from the tree. The
+// per-wave LDS scratch is the wave's traversal stack (16 x 64 words), unused meanwhile. Shadow rays and the counting
+// kernels keep the exact traversal.
+PT_DEV int select64(uint64_t m, int k) {                       // position of the k-th (0-based) set bit of m
+    int pos = 0;
+    for (int w = 32; w; w >>= 1) {
+        const uint64_t low = m & ((1ull << w) - 1ull);
+        const int c = (int)__builtin_popcountll(low);
+        if (k >= c) { k -= c; m >>= w; pos += w; } else m = low;
+    }
+    return pos;
+}
+PT_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// All 64 lanes call this together; `active` says who has a ray. PNode.pad0 / pad1 hold the number of triangles
+// below the left / right child (patched in by the host for scenes that qualify, pt_api.hip).
+template <int N>
+PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool active, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nInternal) {
+    static_assert(N >= 13, "the scratch layout needs 13 x 64 words of the wave's stack");
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const int lane = (int)(threadIdx.x & 63u);
+    lds_i32* W = st.lds - lane;                                  // the wave's 16 x 64 words; field f of lane l at W[f * 64 + l]
+    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // 1. lockstep node walk
+    uint64_t tm = 0ull;
+    if (S.rootRef < 0) tm = active ? ~0ull >> (64 - S.nTris) : 0ull;      // the root is the only leaf
+    else {
+        uint64_t vis = active ? 1ull << (uint32_t)S.rootRef : 0ull;
+        for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
+            const bool v = ((vis >> i) & 1ull) != 0ull;
+            if (__builtin_amdgcn_ballot_w64(v) == 0ull) continue;
+            const NodeData n = load_node<true>(S, C, i);          // uniform address: an LDS broadcast
+            float tL, tR;
+            const bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL) && v;
+            const bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR) && v;
+            const int32_t left = __builtin_amdgcn_readfirstlane(f2i(n.d.x)), right = __builtin_amdgcn_readfirstlane(f2i(n.d.y));
+            const int32_t cntL = __builtin_amdgcn_readfirstlane(f2i(n.d.z)), cntR = __builtin_amdgcn_readfirstlane(f2i(n.d.w));
+            const uint64_t bL = left >= 0 ? 1ull << (uint32_t)left : (~0ull >> (64 - cntL)) << (uint32_t)(~left);
+            const uint64_t bR = right >= 0 ? 1ull << (uint32_t)right : (~0ull >> (64 - cntR)) << (uint32_t)(~right);
+            if (left >= 0) vis |= hL ? bL : 0ull; else tm |= hL ? bL : 0ull;
+            if (right >= 0) vis |= hR ? bR : 0ull; else tm |= hR ? bR : 0ull;
+        }
+    }
+    // 2. deal the tests out: lane j takes tests [j * per, (j + 1) * per) of the wave's sequence (rays in lane order,
+    //    triangles in index order) — consecutive tests mostly belong to one ray, which the lane keeps in registers
+    const int n = (int)__builtin_popcountll(tm);
+    int pre = n;                                                  // inclusive prefix sum: DPP inside rows of 16, then the row totals
+    pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, true);      // row_shr:1
+    pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, true);      // row_shr:2
+    pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, true);      // row_shr:4
+    pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, true);      // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(pre, 15), r1 = __builtin_amdgcn_readlane(pre, 31), r2 = __builtin_amdgcn_readlane(pre, 47);
+    pre += (lane >= 16 ? r0 : 0) + (lane >= 32 ? r1 : 0) + (lane >= 48 ? r2 : 0);
+    const int total = __builtin_amdgcn_readlane(pre, 63);         // wave-uniform
+    pre -= n;                                                    // exclusive prefix
+    W[0 * 64 + lane] = __builtin_bit_cast(int32_t, o.x); W[1 * 64 + lane] = __builtin_bit_cast(int32_t, o.y); W[2 * 64 + lane] = __builtin_bit_cast(int32_t, o.z);
+    W[3 * 64 + lane] = __builtin_bit_cast(int32_t, d.x); W[4 * 64 + lane] = __builtin_bit_cast(int32_t, d.y); W[5 * 64 + lane] = __builtin_bit_cast(int32_t, d.z);
+    W[6 * 64 + lane] = (int32_t)(uint32_t)tm; W[7 * 64 + lane] = (int32_t)(uint32_t)(tm >> 32);
+    W[8 * 64 + lane] = pre;
+    lds_u64* kLo = (lds_u64*)(W + 9 * 64);                        // min over (t bits, triangle index)
+    lds_u64* kHi = (lds_u64*)(W + 11 * 64);                       // min over (t bits, 63 - triangle index)
+    kLo[lane] = ~0ull; kHi[lane] = ~0ull;
+    wave_lds_sync();
+    const int per = (total + 63) >> 6;
+    int p = lane * per;
+    const int pEnd = (p + per < total) ? p + per : total;
+    int l = 0;
+    uint64_t rem = 0ull;
+    V3 ro = v3(0.0f), rd = v3(0.0f);
+    if (p < pEnd) {
+        for (int s = 32; s; s >>= 1) { const int cand = l + s; if (W[8 * 64 + cand] <= p) l = cand; }      // owner of test p: the last lane whose exclusive prefix is <= p
+        const uint64_t tml = (uint64_t)(uint32_t)W[6 * 64 + l] | ((uint64_t)(uint32_t)W[7 * 64 + l] << 32);
+        rem = tml & ~((1ull << select64(tml, p - W[8 * 64 + l])) - 1ull);                                    // its triangles from the (p - prefix)-th on
+        ro = v3(__builtin_bit_cast(float, W[0 * 64 + l]), __builtin_bit_cast(float, W[1 * 64 + l]), __builtin_bit_cast(float, W[2 * 64 + l]));
+        rd = v3(__builtin_bit_cast(float, W[3 * 64 + l]), __builtin_bit_cast(float, W[4 * 64 + l]), __builtin_bit_cast(float, W[5 * 64 + l]));
+    }
+    for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
+        if (p < pEnd) {
+            while (rem == 0ull) {                                 // next ray that has tests (there is one: p < total)
+                l++;
+                rem = (uint64_t)(uint32_t)W[6 * 64 + l] | ((uint64_t)(uint32_t)W[7 * 64 + l] << 32);
+                ro = v3(__builtin_bit_cast(float, W[0 * 64 + l]), __builtin_bit_cast(float, W[1 * 64 + l]), __builtin_bit_cast(float, W[2 * 64 + l]));
+                rd = v3(__builtin_bit_cast(float, W[3 * 64 + l]), __builtin_bit_cast(float, W[4 * 64 + l]), __builtin_bit_cast(float, W[5 * 64 + l]));
+            }
+            const int ti = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            const TriData q = load_tri<true>(S, C, ti);
+            float t, u, v;
+            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), ro, rd, t, u, v);
+            if (ok && (t < max_t)) {
+                const uint64_t tb = (uint64_t)f2u(t) << 32;           // t > 0: the bit pattern orders like the value
+                __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(63 - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            p++;
+        }
+    }
+    wave_lds_sync();
+    // 3. the winner. If more than one triangle returned the minimum, the reference keeps the one it visits first:
+    //    collect the tied set (re-test the ray's own triangles, rare) and walk down from the root — where the set has
+    //    members on both sides both children were hit, and the reference enters the nearer one (`tL < tR`, else the
+    //    right one) first; in a leaf the lowest index wins.
+    if (active) {
+        const uint64_t a = kLo[lane], b = kHi[lane];
+        hit.tri = -1;
+        if (a != ~0ull) {
+            int win = (int)(uint32_t)a;
+            const int last = 63 - (int)(uint32_t)b;
+            if (win != last) {
+                const uint32_t tmin = (uint32_t)(a >> 32);
+                uint64_t tied = 0ull;
+                for (uint64_t rest = tm; rest; rest &= rest - 1ull) {
+                    const int ti = __builtin_ctzll(rest);
+                    const TriData q = load_tri<true>(S, C, ti);
+                    float t, u, v;
+                    const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+                    if (ok && (t < max_t) && f2u(t) == tmin) tied |= 1ull << ti;
+                }
+                int32_t ref = S.rootRef;
+                int lo = 0;                                        // first triangle of the current subtree (leaf order = left to right)
+                while (ref >= 0) {
+                    const NodeData nd = load_node<true>(S, C, ref);
+                    const int mid = lo + f2i(nd.d.z), hi = mid + f2i(nd.d.w);
+                    const uint64_t inL = tied & ((~0ull >> (64 - (mid - lo))) << lo), inR = tied & ((~0ull >> (64 - (hi - mid))) << mid);
+                    bool goLeft = inR == 0ull;
+                    if (inL != 0ull && inR != 0ull) {
+                        float tL, tR;
+                        slab(nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, o, inv, tL);
+                        slab(nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, o, inv, tR);
+                        goLeft = tL < tR;
+                    }
+                    ref = goLeft ? f2i(nd.d.x) : f2i(nd.d.y);
+                    if (!goLeft) lo = mid;
+                    tied = goLeft ? inL : inR;
+                }
+                win = __builtin_ctzll(tied);                       // inside the leaf: the first in leaf order
+            }
+            const TriData q = load_tri<true>(S, C, win);
+            float t, u, v;
+            moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            hit.t = t; hit.u = u; hit.v = v;
+            hit.tri = (int32_t)(f2u(q.e.y) & 0x7fffffffu);
+            hit.material = f2i(q.e.z);
+        }
+    }
+    wave_lds_sync();                                              // the scratch becomes the stack again
+}
+
 // ---- unified per-lane traverser -------------------------------------------------------------
 // The same two traversals as above as ONE resumable state machine, so that a lane can run its
 // rays back to back inside a single loop: the megakernel traces a bounce's shadow ray and the next

@@ -153,8 +153,10 @@ typedef int (*pt_progress_fn)(int samples_done, void* user);
 int pt_launch_progressive(int integrator, int maxDepth, pt_camera camera, pt_scene* scene, int numSample, int useMIS, int w, int h,
                           void* d_colors, int chunk_spp, pt_progress_fn progress, void* user);
 
-/* Same as pt_render plus per-pixel counters (w*h x 8 uint32: rays_closest, rays_shadow,
- * node_pops, box_tests, tri_tests, hits, rng_draws, iterations) for parity checks. */
+/* The same image from the COUNTING instantiations of the kernels (stack walk everywhere, no time slices), plus the
+ * per-pixel counters (w*h x 8 uint32: rays_closest, rays_shadow, node_pops, box_tests, tri_tests, hits, rng_draws,
+ * iterations; out_counters may be NULL) and the totals of pt_get_counters, for parity checks. pt_render itself runs
+ * the kernels that bench.py times and leaves the counters alone. */
 int pt_render_counted(pt_scene* scene, const pt_camera* camera, int w, int h, int spp, int max_depth,
                       int integrator, int use_mis, uint64_t seed, const pt_tile_range* tiles,
                       float* out_rgba_sum, uint32_t* out_counters);
@@ -173,7 +175,8 @@ float pt_last_kernel_ms(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
- * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing). For labelling measurements. */
+ * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing), bit 6 = it used the FLAT
+ * closest-hit traversal (LDS-resident scenes with at most 64 nodes and triangles). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a

@@ -225,6 +225,33 @@ def test_loop_exits_and_refill(api, gpu_ready, monkeypatch, knobs):
 
 
 @pytest.mark.parametrize("integrator", [0, 2])
+def test_flat_kernel_and_ties(api, oracle, gpu_ready, scene_dir, monkeypatch, integrator):
+    """pt_trace.h FLAT (scenes with at most 64 nodes / triangles): lockstep node walk + dealt-out triangle tests must
+    give the stack walk's image bit for bit — also where two triangles return the SAME t and the reference keeps the
+    one it visits first: the tall box exists twice, once diffuse and once as a mirror / as glass."""
+    from cudapathtracer_amd import scenes
+    cfgs = [scenes.cornell(os.path.join(scene_dir, "twin19"), 40, 24, 6, 6, doubled=19, name="twin19")["config"],
+            scenes.cornell(os.path.join(scene_dir, "twin5"), 33, 17, 5, 8, doubled=5, tall_material=19, ceiling_light=True, name="twin5")["config"]]
+    for cfg in cfgs:
+        gs, hs, osc = _scene_pair(api, oracle, cfg)
+        i = hs.info
+        assert i["n_tris"] <= 64
+        col, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
+        assert gs.flags()["flat"] and gs.flags()["onchip"], gs.flags()
+        ocol, ocnt, _ = osc.render(integrator=integrator, counters=True, threads=8)
+        assert_bits_equal(col, ocol, cfg)
+        col2, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator, counters=True)   # the stack walk
+        assert np.array_equal(cnt, ocnt) and not gs.flags()["flat"]
+        assert_bits_equal(col2, ocol, cfg)
+        monkeypatch.setenv("PT_FLAT", "0")
+        gs0 = api.Scene(hs)
+        col3, _ = gs0.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
+        assert not gs0.flags()["flat"]
+        assert_bits_equal(col3, ocol, cfg)
+        monkeypatch.delenv("PT_FLAT")
+
+
+@pytest.mark.parametrize("integrator", [0, 2])
 def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integrator):
     from cudapathtracer_amd import scenes
     cfgs = [scenes.blob_in_box(os.path.join(scene_dir, "blob3r"), 45, 27, 3, 6, subdiv=3, name="blob3r")["config"],      # ragged size
