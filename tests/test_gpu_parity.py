@@ -251,6 +251,27 @@ def test_flat_kernel_and_ties(api, oracle, gpu_ready, scene_dir, monkeypatch, in
         monkeypatch.delenv("PT_FLAT")
 
 
+def test_flat_kernel_single_leaf_scene(api, oracle, gpu_ready):
+    """The whole scene is ONE leaf (root ref < 0, no internal node): the FLAT kernel's degenerate case."""
+    arr = _chain_arrays(api, n=3)
+    n = 4                                            # 3 stacked triangles + the light
+    nodes = np.zeros((1, 12), np.float32)
+    pts = arr["points"][:, :3].reshape(-1, 3, 3)
+    nodes[0, 0:3] = pts.min(axis=(0, 1)) - 1e-6; nodes[0, 4:7] = pts.max(axis=(0, 1)) + 1e-6
+    nodes.view(np.int32)[0, 8:12] = [-1, -1, 0, n]
+    arr = dict(arr, bvh=nodes, indices=np.arange(n, dtype=np.int32))
+    gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
+    cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
+    col, _ = gs.render(cam, 24, 16, 4, 5)
+    assert gs.flags()["flat"], gs.flags()
+    ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=24, height=16, spp=4, max_depth=5, counters=True)
+    assert_bits_equal(col, ocol, "single-leaf scene, FLAT kernel")
+    col2, cnt = gs.render(cam, 24, 16, 4, 5, counters=True)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col2, ocol, "single-leaf scene, stack walk")
+    assert ocnt[..., 5].sum() > 50
+
+
 @pytest.mark.parametrize("integrator", [0, 2])
 def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integrator):
     from cudapathtracer_amd import scenes
