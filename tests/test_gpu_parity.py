@@ -558,6 +558,44 @@ def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir, monkeypatch
         assert_bits_equal(f, frames[0], "scheduling reached the image")
 
 
+def test_full_frame_kernels_agree_on_a_scene_in_hbm(api, gpu_ready, scene_dir, monkeypatch):
+    """BASELINE C3's geometry class (82 k triangles, tree in HBM) at 1920x1080, 3 spp, depth 6: the image must not depend
+    on which instantiation rendered it — the production kernel (12-wave workgroups, loop exits, resumable traversal),
+    the same with plain loops and the shadow ray inside the bounce, the 4-wave kernel, the counting kernel, the
+    FLAT switch (a no-op here) and the wavefront variant. Plus the counter identities that need no oracle."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.blob_in_box(os.path.join(scene_dir, "b82"), 1920, 1080, 3, 6, name="b82")["config"]
+    hs = api.HostScene(cfg)
+    assert hs.info["n_tris"] > 80000
+    knobs = ("PT_REFILL", "PT_NODE_KEEP", "PT_TRI_KEEP", "PT_WAVES_HBM", "PT_SLICE_ITERS", "PT_PERSISTENT")
+    frames = []
+    for env in ({}, {"PT_REFILL": "0", "PT_NODE_KEEP": "0", "PT_TRI_KEEP": "0"}, {"PT_WAVES_HBM": "0"}, {"PT_REFILL": "1", "PT_REFILL_KEEP": "12", "PT_SLICE_ITERS": "64"},
+                {"PT_PERSISTENT": "0"}):
+        for k in knobs + ("PT_REFILL_KEEP",):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sc = api.Scene(hs)
+        a, _ = sc.render(hs.camera(), 1920, 1080, 3, 6)
+        fl = sc.flags()
+        assert not fl["onchip"] and not fl["flat"]
+        assert fl["refill"] == (env.get("PT_REFILL", "1") != "0") and fl["hbm_kernel"] == (env.get("PT_WAVES_HBM", "1") != "0"), (env, fl)
+        frames.append(a)
+        if not env:
+            b, cnt = sc.render(hs.camera(), 1920, 1080, 3, 6, counters=True)          # counting kernel
+            frames.append(b)
+            assert int(cnt[..., 0].sum()) == int(cnt[..., 7].sum())                    # one closest-hit ray per bounce iteration
+            assert np.all(cnt[..., 3] % 2 == 0) and np.all(cnt[..., 5] <= cnt[..., 0])  # boxes in pairs; hits <= rays
+            w, _ = sc.set_variant("wavefront").render(hs.camera(), 1920, 1080, 3, 6)
+            frames.append(w)
+        sc.close()
+    for f in frames[1:]:
+        assert_bits_equal(f, frames[0], "the instantiation reached the image")
+    bad = int((~np.isfinite(frames[0][..., :3])).any(axis=-1).sum())
+    print("non-finite pixels:", bad)
+    assert bad < 2073600 // 10000 and np.nansum(frames[0][..., :3]) > 0, bad      # (the reference's arithmetic has no guards either)
+
+
 def test_full_size_properties(api, gpu_ready, scene_dir):
     """BASELINE C2 geometry at full 1920x1080 (2 spp): properties that need no oracle run."""
     from cudapathtracer_amd import scenes
