@@ -20,7 +20,10 @@ constexpr int kStackLds = PT_STACK_LDS;
 #define PT_WAVES_HBM 6             // waves per SIMD of the instantiation for scenes that do not fit the LDS cache (0 = use the 4-wave kernel)
 #endif
 constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
-constexpr int kStackLdsHbm = 8;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
+#ifndef PT_STACK_LDS_HBM
+#define PT_STACK_LDS_HBM 8
+#endif
+constexpr int kStackLdsHbm = PT_STACK_LDS_HBM;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
 constexpr int kCacheBytes = PT_CACHE_BYTES;
 // The kernel for scenes in HBM runs in workgroups of PT_WG_WAVES_HBM waves (default 12: two workgroups per CU at 6
