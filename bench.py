@@ -58,7 +58,7 @@ def host_threads():
     return min(n, int(os.environ.get("PT_BENCH_CPU_THREADS", "16")))
 
 
-def cpu_baseline(cfg, info, seconds_budget=15.0):
+def cpu_baseline(cfg, info, seconds_budget=25.0):
     """The oracle (kind "port": this repo's CPU restatement; the CUDA reference cannot be built here)
     on a bounded sample of the workload: the full frame at a reduced sample count."""
     from oracle import oracle_py as O          # checker / reported baseline only
