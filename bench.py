@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="megakernel", choices=["megakernel", "wavefront"],
                     help="kernel organisation (SURVEY §8 f-1 A/B); the headline is the megakernel")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostic: pt_set_option on the scene (kernel selection / scheduling A/B, include/pt_api.h); the JSON lists them")
     ap.add_argument("--culling", action="store_true",
                     help="diagnostic: opt-in box culling (pt_set_culling) - NOT the reference's visiting set, never the headline")
     args = ap.parse_args()
@@ -137,9 +139,8 @@ def main():
     w, h, md = info["width"], info["height"], info["max_depth"]
     spp = args.spp or info["spp"]
     cam = host.camera()
-    scene = api.Scene(host).set_variant(args.variant)           # scene resident in HBM from here on
-    if args.culling:
-        scene.set_culling(True)
+    opts = api.parse_options(args.opt)
+    scene = api.Scene(host, options=opts).set_variant(args.variant)           # scene resident in HBM from here on
     if args.culling:
         scene.set_culling(True)
 

@@ -114,6 +114,8 @@ def lib():
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
     L.pt_scene_flags.argtypes = [vp]
     L.pt_set_culling.argtypes = [vp, i32]
+    L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.pt_get_option.argtypes = [vp, C.c_char_p, vp]
     L.pt_debug_stamps.argtypes = [vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
@@ -265,14 +267,30 @@ class HostScene:
 class Scene:
     """Device-resident, re-packed scene (pt_scene). Created on the CURRENT HIP device."""
 
-    def __init__(self, host: HostScene | None = None, desc: SceneDesc | None = None):
+    def __init__(self, host: HostScene | None = None, desc: SceneDesc | None = None, options: dict | None = None):
         d = host.desc if host is not None else desc
         self.h = lib().pt_scene_create(C.byref(d))
         if not self.h:
             raise PtError("pt_scene_create failed: " + lib().pt_last_error().decode(errors="replace"))
+        self.set_options(options)
+
+    def set_option(self, name, value):
+        """pt_set_option: kernel-selection / scheduling options by name (include/pt_api.h lists them)."""
+        _check(lib().pt_set_option(self.h, name.encode(), int(value)), "pt_set_option(%s)" % name)
+        return self
+
+    def set_options(self, options):
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+        return self
+
+    def get_option(self, name):
+        out = np.zeros(1, np.int32)
+        _check(lib().pt_get_option(self.h, name.encode(), _p(out)), "pt_get_option(%s)" % name)
+        return int(out[0])
 
     @staticmethod
-    def from_mesh(host: "HostScene", max_leaf_size=None):
+    def from_mesh(host: "HostScene", max_leaf_size=None, options=None):
         """pt_scene_create_from_mesh: BVH build (reference tree) and re-layout on the device from the host scene's
         geometry; its host-built tree is not used. Returns the scene; `.build_stats` has the builder's numbers."""
         st = np.zeros(1, BUILD_STATS)
@@ -282,6 +300,7 @@ class Scene:
             raise PtError("pt_scene_create_from_mesh failed: " + lib().pt_last_error().decode(errors="replace"))
         sc = Scene.__new__(Scene)
         sc.h = h; sc._keep = host
+        sc.set_options(options)
         sc.build_stats = {f: st[0][f].item() for f in BUILD_STATS.names}
         return sc
 
@@ -297,7 +316,7 @@ class Scene:
         return buf
 
     @staticmethod
-    def from_arrays(arrays):
+    def from_arrays(arrays, options=None):
         """pt_scene_create straight from arrays in the reference's layouts (dict of buffers: points,
         normals, uvs, mesh, lights, bvh, indices, materials[, textures])."""
         a = {k: np.ascontiguousarray(v).view(np.uint8) for k, v in arrays.items()}
@@ -312,7 +331,7 @@ class Scene:
         d.materials, d.n_materials = a["materials"].ctypes.data, a["materials"].size // 176
         t = a.get("textures")
         d.textures, d.n_texels = (t.ctypes.data if t is not None and t.size else None), (t.size // 16 if t is not None else 0)
-        return Scene(desc=d)
+        return Scene(desc=d, options=options)
 
     @staticmethod
     def from_config(config_path, base_dir=None, render_number=0):
@@ -401,7 +420,12 @@ class Scene:
         return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64)}
 
     def last_kernel_ms(self):
-        return float(lib().pt_last_kernel_ms(self.h))
+        """Device time of the last launch; raises if that launch did not finish its frame (tile-queue timeout).
+        Callers of render_tiles_device (asynchronous) learn about an incomplete frame here."""
+        ms = float(lib().pt_last_kernel_ms(self.h))
+        if ms < 0.0:
+            raise PtError("pt_last_kernel_ms: " + (lib().pt_last_error().decode(errors="replace") or "the last launch failed"))
+        return ms
 
     # -- probes ---------------------------------------------------------------------------------
     def trace_closest(self, rays):
@@ -434,6 +458,17 @@ class Scene:
         out = np.zeros((n, 4), np.float32)
         _check(lib().pt_probe_bsdf_eval(self.h, n, _p(material), _p(wi), _p(wo), eta_i, eta_t, _p(out)), "pt_probe_bsdf_eval")
         return out
+
+
+def parse_options(pairs):
+    """["flat=0", "waves_hbm=2"] -> {"flat": 0, "waves_hbm": 2} for the --opt flag of bench.py and tools/."""
+    out = {}
+    for p in pairs or []:
+        for item in p.split(","):
+            if item:
+                k, _, v = item.partition("=")
+                out[k.strip()] = int(v)
+    return out
 
 
 def untile_device(w, h, d_tiles_ptr, d_colors_ptr, tiles=None, stream=0):

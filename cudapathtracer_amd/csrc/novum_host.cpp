@@ -19,6 +19,8 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -439,12 +441,22 @@ bool load_bmp(const std::string& file, std::vector<pt_float4>& px, int& w, int& 
     bool ok = fread(hd, 1, 54, f) == 54 && hd[0] == 'B' && hd[1] == 'M';
     uint16_t bpp = 0; int32_t bw = 0, bh = 0;
     if (ok) { std::memcpy(&bpp, hd + 28, 2); std::memcpy(&bw, hd + 18, 4); std::memcpy(&bh, hd + 22, 4); ok = bpp == 24 && bw > 0 && bh > 0; }
+    // The header is untrusted input: a texture of more than 2^26 texels (1 GB as float4), or one whose pixel rows the file
+    // cannot hold, is treated like a missing file (the reference's Image(0,0)) instead of overflowing `3*bw`, `bw*bh` or
+    // throwing bad_alloc across the C ABI. A file that ends inside the LAST rows still loads: the reference keeps whatever
+    // its row buffer held from the previous fread there, this loader zero-fills those rows (Appendix-D style definition).
     if (ok) {
-        const int row = (3 * bw + 3) & ~3;
+        const long long texels = (long long)bw * (long long)bh, rowBytes = (3ll * bw + 3ll) & ~3ll;
+        long long fileBytes = -1;
+        if (fseek(f, 0, SEEK_END) == 0) fileBytes = ftell(f);
+        ok = texels <= (1ll << 26) && fileBytes >= 54 + rowBytes && fseek(f, 54, SEEK_SET) == 0;
+    }
+    if (ok) {
+        const size_t row = ((size_t)3 * (size_t)bw + 3) & ~(size_t)3;
         std::vector<unsigned char> line(row);
         px.assign((size_t)bw * bh, pt_float4{0, 0, 0, 0});
         for (int y = 0; y < bh; y++) {
-            if (fread(line.data(), 1, row, f) != (size_t)row) std::fill(line.begin(), line.end(), (unsigned char)0);
+            if (fread(line.data(), 1, row, f) != row) std::fill(line.begin(), line.end(), (unsigned char)0);
             for (int x = 0; x < bw; x++) {
                 float b = line[x * 3 + 0] / 255.0f, g = line[x * 3 + 1] / 255.0f, r = line[x * 3 + 2] / 255.0f;
                 px[(size_t)(bh - 1 - y) * bw + x] = pt_float4{powf(r, 2.2f), powf(g, 2.2f), powf(b, 2.2f), 1.0f};
@@ -464,10 +476,28 @@ float aces(float c) { return clamp01((c * (2.51f * c + 0.03f)) / (c * (2.43f * c
 
 extern "C" {
 
+int pt_fail_(int code, const char* msg);             // pt_api.hip: sets pt_last_error()
+
+static novum_scene* scene_load(const char* config_path, const char* base_dir, int render_number, int bvh_builder);
+
+// No C++ exception may cross the C ABI (std::terminate in the host process): out-of-memory or a malformed
+// file that makes a container throw ends as nullptr + pt_last_error().
 novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, int render_number, int bvh_builder) {
+    try {
+        return scene_load(config_path, base_dir, render_number, bvh_builder);
+    } catch (const std::exception& e) {
+        pt_fail_(-1, (std::string("novum_scene_load: ") + e.what()).c_str());
+    } catch (...) {
+        pt_fail_(-1, "novum_scene_load: unknown exception");
+    }
+    return nullptr;
+}
+
+static novum_scene* scene_load(const char* config_path, const char* base_dir, int render_number, int bvh_builder) {
     if (!config_path) return nullptr;
-    novum_scene* S = new novum_scene();
-    if (!parse_config(config_path, S->cfg)) { delete S; return nullptr; }
+    std::unique_ptr<novum_scene> owner(new novum_scene());      // freed on every early return and on a throw
+    novum_scene* S = owner.get();
+    if (!parse_config(config_path, S->cfg)) { return nullptr; }
     std::string base;
     if (base_dir) base = base_dir;
     else { std::string p = config_path; size_t k = p.find_last_of('/'); base = (k == std::string::npos) ? "." : p.substr(0, k); }
@@ -482,6 +512,7 @@ novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, 
         load_bmp(base + "/" + kTextures[i], px, tW[i], tH[i]);
         S->textures.insert(S->textures.end(), px.begin(), px.end());
         tStart[i] = cursor;
+        if ((long long)cursor + (long long)tW[i] * tH[i] > 0x7fffffffll) { pt_fail_(-1, "novum_scene_load: the textures exceed 2^31 texels"); return nullptr; }
         cursor += tW[i] * tH[i];
     }
     material_table(*S, tStart, tW, tH);
@@ -492,7 +523,7 @@ novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, 
         float off[3] = {0.0f, emissive ? -0.01f * render_number : 0.0f, 0.0f};        // main.cu:476-478
         read_obj(p, *S, e, m.material, off);
     }
-    if (S->mesh.empty()) { fprintf(stderr, "Error: No triangles loaded.\n"); delete S; return nullptr; }
+    if (S->mesh.empty()) { fprintf(stderr, "Error: No triangles loaded.\n"); return nullptr; }
     S->indices.resize(S->mesh.size());
     for (size_t i = 0; i < S->mesh.size(); i++) S->indices[i] = (int32_t)i;
     if (bvh_builder == NOVUM_BVH_DEVICE) {                        // f-4: same tree, built on the GPU
@@ -500,7 +531,7 @@ novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, 
         pt_bvh_build_stats st{};
         int k = pt_bvh_build_device(S->points.data(), (int)S->points.size(), S->mesh.data(), (int)S->mesh.size(), c.leafSize,
                                     PT_BVH_REFERENCE_TREE, S->bvh.data(), (int)S->bvh.size(), S->indices.data(), &st);
-        if (k <= 0) { fprintf(stderr, "novum_scene_load: %s\n", pt_last_error()); delete S; return nullptr; }
+        if (k <= 0) { fprintf(stderr, "novum_scene_load: %s\n", pt_last_error()); return nullptr; }
         S->bvh.resize(k);
         S->largestLeaf = st.largest_leaf; S->backups = st.backups;
     } else {
@@ -509,7 +540,7 @@ novum_scene* novum_scene_load_ex(const char* config_path, const char* base_dir, 
         b.build();
     }
     S->treeDepth = tree_depth(S->bvh);
-    return S;
+    return owner.release();
 }
 
 novum_scene* novum_scene_load(const char* config_path, const char* base_dir, int render_number) {

@@ -62,24 +62,25 @@ struct pt_scene {
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
-    int schedMask = 31;          // PT_SCHED_MASK: scheduling checks every schedMask + 1 bounce iterations (tests use 3)
-    bool sliceAlways = true;     // PT_SLICE_ALWAYS=0: slices only once no fresh tile is left
-    bool wavesHbmOk = PT_WAVES_HBM > 0;   // PT_WAVES_HBM=0 (env): scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
-    int nodeKeep = 8, triKeep = 8;        // PT_NODE_KEEP / PT_TRI_KEEP (pt_trace.h: LoopExit)
-    int refill = 1, refillKeep = 4;       // PT_REFILL / PT_REFILL_KEEP: REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
-    bool cull = false;                    // pt_set_culling / PT_CULL=1: opt-in, not parity-exact by construction
-    bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / PT_FLAT=0 turns them off (A/B)
+    // Everything below is set per scene through pt_set_option (names in quotes); the library reads no environment variable.
+    int schedMask = 31;          // "sched_mask": scheduling checks every schedMask + 1 bounce iterations (tests use 3)
+    bool sliceAlways = true;     // "slice_always" 0: slices only once no fresh tile is left
+    bool wavesHbmOk = PT_WAVES_HBM > 0;   // "waves_hbm" 0: scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
+    int nodeKeep = 8, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
+    int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
+    bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
+    bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0;
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
-    bool wavesHbmForce = false;           // PT_WAVES_HBM=2 (env): ... and the 6-wave kernel whatever the tile count (tests)
-    bool onchipOk = true;        // PT_ONCHIP=0: never pick the LDS-only kernel instantiation (A/B)
+    bool wavesHbmForce = false;           // "waves_hbm" 2: ... and the 6-wave kernel whatever the tile count (tests)
+    bool onchipOk = true;        // "onchip" 0: never pick the LDS-only kernel instantiation (A/B)
     int nTrisPacked = 0;
-    int sliceIters = 512;        // PT_SLICE_ITERS: time slice of the tile queue once no fresh tile is left (0 = off)
-    int lptPrio = 2;             // PT_LPT_PRIO: 0 no issue-priority steering, 1 once no fresh tile is left, 2 always (A/B)
-    bool persistent = true;      // PT_PERSISTENT=0: one tile per wave, workgroups launched per 4 tiles (A/B)
-    bool xcdBands = false;       // PT_XCD_BANDS=1: one contiguous band of tiles per XCD (A/B; loses to interleaving)
-    bool deferShadow = false;    // PT_DEFER_SHADOW=1: megakernel traces shadow + extension ray as a pair (A/B; slower)
+    int sliceIters = 512;        // "slice_iters": time slice of the tile queue (0 = off)
+    int lptPrio = 2;             // "lpt_prio": 0 no issue-priority steering, 1 once no fresh tile is left, 2 always (A/B)
+    bool persistent = true;      // "persistent" 0: one tile per wave, workgroups launched per 4 tiles (A/B)
+    bool xcdBands = false;       // "xcd_bands" 1: one contiguous band of tiles per XCD (A/B; loses to interleaving)
+    bool deferShadow = false;    // "defer_shadow" 1: megakernel traces shadow + extension ray as a pair (A/B; slower)
     float lastKernelMs = 0.0f;
     bool evPending = false;                            // ev0/ev1 recorded, elapsed time not read yet
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -351,21 +352,6 @@ static pt_scene* create_scene(const pt_scene_desc* desc, int deviceLeaf, pt_bvh_
         return nullptr;
     }
     if (repack(s, desc, deviceLeaf, stats) != 0) { pt_scene_destroy(s); return nullptr; }
-    if (const char* e = getenv("PT_DEFER_SHADOW")) s->deferShadow = (e[0] == '1');
-    if (const char* e = getenv("PT_SCHED_MASK")) { int m = atoi(e); if (m >= 0 && ((m + 1) & m) == 0) s->schedMask = m; }
-    if (const char* e = getenv("PT_WAVES_HBM")) { s->wavesHbmOk = (e[0] != '0') && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && e[0] == '2'; }
-    if (const char* e = getenv("PT_ONCHIP")) s->onchipOk = (e[0] != '0');
-    if (const char* e = getenv("PT_CULL")) s->cull = (e[0] == '1');
-    if (const char* e = getenv("PT_NODE_KEEP")) s->nodeKeep = std::min(15, std::max(0, atoi(e)));
-    if (const char* e = getenv("PT_TRI_KEEP")) s->triKeep = std::min(15, std::max(0, atoi(e)));
-    if (const char* e = getenv("PT_FLAT")) s->flatWanted = (e[0] != '0');
-    if (const char* e = getenv("PT_REFILL")) s->refill = atoi(e);
-    if (const char* e = getenv("PT_REFILL_KEEP")) s->refillKeep = std::min(15, std::max(0, atoi(e)));
-    if (const char* e = getenv("PT_SLICE_ALWAYS")) s->sliceAlways = (e[0] != '0');
-    if (const char* e = getenv("PT_SLICE_ITERS")) s->sliceIters = std::max(0, atoi(e));
-    if (const char* e = getenv("PT_LPT_PRIO")) s->lptPrio = atoi(e);     // 0 off, 1 once no fresh tile is left, 2 always
-    if (const char* e = getenv("PT_PERSISTENT")) s->persistent = (e[0] != '0');
-    if (const char* e = getenv("PT_XCD_BANDS")) s->xcdBands = (e[0] == '1');
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->numCU = prop.multiProcessorCount;
@@ -575,7 +561,7 @@ static int launch_on_colors(pt_scene* s, const pt_camera* cam, int w, int h, int
     if (int r = render_tiles(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, t, s->tilebuf.p, d_pixcnt, count, nullptr, false)) return r;
     HIP_OK(launch_untile(w, h, t, (const float4*)s->tilebuf.p, (float4*)d_colors, nullptr));
     HIP_OK(hipDeviceSynchronize());                 // cudaDeviceSynchronize, deviceCode.cu:608
-    return 0;
+    return queue_error(s);                          // a tile-queue timeout means an incomplete frame: never report success
 }
 
 // The reference's launchers with their progressive hook (deviceCode.cu:568-606): the sample loop runs
@@ -597,6 +583,7 @@ int pt_launch_progressive(int integrator, int maxDepth, pt_camera camera, pt_sce
         if (int r = render_tiles(s, &camera, w, h, n, maxDepth, integrator, useMIS, 103033ull, t, s->tilebuf.p, nullptr, false, nullptr, done > 0)) return r;
         HIP_OK(launch_untile(w, h, t, (const float4*)s->tilebuf.p, (float4*)d_colors, nullptr));
         HIP_OK(hipDeviceSynchronize());
+        if (int r = queue_error(s)) return r;
         done += n;
         if (progress && progress(done, user) != 0) break;
     }
@@ -626,7 +613,6 @@ static int render_host(pt_scene* s, const pt_camera* cam, int w, int h, int spp,
     }
     if (int r = launch_on_colors(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, s->colors.p, dpc, count)) return r;
     HIP_OK(hipMemcpy(out, s->colors.p, px * sizeof(float4), hipMemcpyDeviceToHost));
-    if (int r = queue_error(s)) return r;
     if (outCounters) {
         std::vector<uint32_t> tmp((size_t)t.count * 512);
         HIP_OK(hipMemcpy(tmp.data(), dpc, tmp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -691,6 +677,72 @@ static int queue_error(pt_scene* s) {
 int pt_set_culling(pt_scene* s, int on) {
     if (!s) return fail(-1, "null scene");
     s->cull = on != 0;
+    return 0;
+}
+
+// Per-scene kernel-selection and scheduling options (round 1 read these from the environment of the host process; an
+// environment variable must not be able to change what a library renders, so they are explicit calls now). Only
+// "culling" can reach the image (pt_set_culling); every other option selects between instantiations / schedules that
+// are bit-identical by construction and by test.
+namespace {
+struct OptionRef { const char* name; int lo, hi; };
+const OptionRef kOptions[] = {
+    {"flat", 0, 1}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
+    {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1},
+};
+int option_index(const char* name) {
+    if (!name) return -1;
+    for (size_t i = 0; i < sizeof(kOptions) / sizeof(kOptions[0]); i++) if (!strcmp(kOptions[i].name, name)) return (int)i;
+    return -1;
+}
+}  // namespace
+
+int pt_set_option(pt_scene* s, const char* name, int v) {
+    if (!s) return fail(-1, "null scene");
+    const int k = option_index(name);
+    if (k < 0) return fail(-1, "pt_set_option: unknown option '%s'", name ? name : "(null)");
+    if (v < kOptions[k].lo || v > kOptions[k].hi) return fail(-1, "pt_set_option: %s = %d is outside [%d, %d]", name, v, kOptions[k].lo, kOptions[k].hi);
+    switch (k) {
+        case 0: s->flatWanted = v != 0; break;
+        case 1: s->onchipOk = v != 0; break;
+        case 2: s->wavesHbmOk = v != 0 && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && v == 2; break;
+        case 3: s->refill = v; break;
+        case 4: s->refillKeep = v; break;
+        case 5: s->nodeKeep = v; break;
+        case 6: s->triKeep = v; break;
+        case 7: s->deferShadow = v != 0; break;
+        case 8: s->sliceIters = v; break;
+        case 9: s->sliceAlways = v != 0; break;
+        case 10: if (((v + 1) & v) != 0) return fail(-1, "pt_set_option: sched_mask must be 2^k - 1"); s->schedMask = v; break;
+        case 11: s->lptPrio = v; break;
+        case 12: s->persistent = v != 0; break;
+        case 13: s->xcdBands = v != 0; break;
+        case 14: s->cull = v != 0; break;
+    }
+    return 0;
+}
+
+int pt_get_option(pt_scene* s, const char* name, int* out) {
+    if (!s || !out) return fail(-1, "null argument");
+    switch (option_index(name)) {
+        case 0: *out = s->flatWanted; break;
+        case 1: *out = s->onchipOk; break;
+        case 2: *out = s->wavesHbmForce ? 2 : (s->wavesHbmOk ? 1 : 0); break;
+        case 3: *out = s->refill; break;
+        case 4: *out = s->refillKeep; break;
+        case 5: *out = s->nodeKeep; break;
+        case 6: *out = s->triKeep; break;
+        case 7: *out = s->deferShadow; break;
+        case 8: *out = s->sliceIters; break;
+        case 9: *out = s->sliceAlways; break;
+        case 10: *out = s->schedMask; break;
+        case 11: *out = s->lptPrio; break;
+        case 12: *out = s->persistent; break;
+        case 13: *out = s->xcdBands; break;
+        case 14: *out = s->cull; break;
+        default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
+    }
     return 0;
 }
 

@@ -558,7 +558,11 @@ __global__ void k_sort_load(Arrays A, const int* idx, SortRec r, int P) {
     unsigned long long k = ~0ull;
     if (i < r.end - r.start) {
         int id = idx[r.start + i];
-        k = ((unsigned long long)fkey(comp3(A.cx, A.cy, A.cz, r.axis, id)) << 32) | (unsigned)id;
+        // the host comparator (`ca < cb`, ties by index) holds -0.0f == +0.0f; fkey() alone would order them, so the
+        // zero is canonicalised for THIS key (the bounds keys keep -0 < +0, the rule they share with the host's vmin / vmax)
+        float c = comp3(A.cx, A.cy, A.cz, r.axis, id);
+        if (c == 0.0f) c = 0.0f;
+        k = ((unsigned long long)fkey(c) << 32) | (unsigned)id;
     }
     A.keys[i] = k;
 }

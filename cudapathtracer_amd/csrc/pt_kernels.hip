@@ -107,7 +107,8 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 // write back / invalidate the whole L2 each time — measured 3x slower on the 263 k-triangle scene. Instead
 // every access to queue words and tile state inside the kernel is a relaxed agent-scope atomic (sc1: served
 // at the memory side, never from a possibly stale cache line), slot and item travel in ONE 64-bit word, and
-// "state before the queue entry" is the wave waiting for its own stores (workgroup-scope release = s_waitcnt).
+// "state before the queue entry" is the wave waiting for its own stores: an explicit `s_waitcnt vmcnt(0)` between the
+// last state store and queue_push (see the end of megakernel_body; no fence emits it by itself).
 // Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
 // surface as an error code, never as a hung GPU.
 constexpr int kFreshBit = 1 << 30;
@@ -375,7 +376,13 @@ PT_DEV void megakernel_body(const KParams& P) {
         for (int o = 32; o; o >>= 1) left = max(left, __shfl_xor(left, o));
         if (left > 0) {                                // yielded: somebody else continues this tile
             state_store((uint32_t*)P.left + (size_t)lt * 64 + lane, (uint32_t)samplesLeft, true);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the wave's state stores have landed before the entry appears
+            // "State before the queue entry": the wave waits for its OWN stores — every state word above is an sc1 store
+            // counted in vmcnt (gfx9 counts stores there, in issue order), so vmcnt(0) means the memory side has them all.
+            // An explicit s_waitcnt, not a fence: a workgroup-scope release fence compiles to nothing here (the two sc1
+            // stores came out back to back), an agent-scope one writes back the whole L2 (3x slower). The
+            // "memory" clobber keeps the compiler from moving the queue accesses above it; tests/test_isa.py checks the
+            // instruction order in every non-counting instantiation.
+            asm volatile("; PT_YIELD_STATE_STORED\n\ts_waitcnt vmcnt(0)" ::: "memory");
             queue_push(P.queue, P.queueMask, lt, lane);
         } else if (lane == 0) atomicAdd(&P.queue[2], 1);
     }

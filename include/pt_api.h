@@ -170,7 +170,11 @@ int pt_set_variant(pt_scene* scene, int variant);
 int pt_get_counters(pt_scene* scene, pt_counters* out);
 int pt_reset_counters(pt_scene* scene);
 /* Device time (ms) of the most recent megakernel launch on this scene, from HIP events recorded
- * on the launch stream around that kernel alone; waits for the launch to finish. */
+ * on the launch stream around that kernel alone; waits for the launch to finish. Returns -1 (and
+ * sets pt_last_error) if that launch did not complete its frame — the tile queue's bounded waits
+ * ran out. The blocking launchers return -4 in that case themselves; a caller of the asynchronous
+ * pt_render_tiles_device MUST check here (or through any later blocking launcher) before it uses
+ * the tile buffer. */
 float pt_last_kernel_ms(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
@@ -185,6 +189,25 @@ int pt_scene_flags(pt_scene* scene);
  * 4.6e9 rays, at 1.2-1.6x the speed. A renderer's trade-off, not the reference's image. Applies to the
  * kernel for scenes that do not fit the LDS cache; flag bit 4 of pt_scene_flags reports it. */
 int pt_set_culling(pt_scene* scene, int on);
+/* Per-scene kernel-selection and scheduling options, by name. The library reads NO environment variable: what a
+ * process renders cannot be steered from its environment. Only "culling" (= pt_set_culling) can reach the image; all
+ * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
+ * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
+ *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes (default 1)
+ *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
+ *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
+ *   "refill" 0|1|2        resumable traversal: off / scenes in HBM / also LDS-resident scenes (1)
+ *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (4, 8, 8)
+ *   "defer_shadow" 0|1    trace shadow + extension ray as a pair in the 4-wave kernel (0)
+ *   "slice_iters" n       bounce iterations a wave keeps a tile before it queues it again, 0 = until finished (512)
+ *   "slice_always" 0|1    time slices from the first tile on (1)
+ *   "sched_mask" 2^k-1    a wave looks at the queue every sched_mask + 1 iterations (31)
+ *   "lpt_prio" 0|1|2      issue-priority steering: off / once no fresh tile is left / always (2)
+ *   "persistent" 0|1      persistent waves on the tile queue (1)
+ *   "xcd_bands" 0|1       one contiguous band of tiles per XCD (0)
+ * Returns 0, or < 0 for an unknown name / a value out of range. */
+int pt_set_option(pt_scene* scene, const char* name, int value);
+int pt_get_option(pt_scene* scene, const char* name, int* value);
 /* Diagnostic builds only, eight sums since the last pt_reset_counters; zeros in a normal build.
  * -DPT_STAMPS: s_memtime spent in regeneration, closest-hit traversal, bounce logic (incl. the shadow ray), then the
  * sum of wave lifetimes, ~(earliest start) and the latest end on the 100 MHz wall clock, 0, 0 (tools/stamps.py).

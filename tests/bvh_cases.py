@@ -82,6 +82,20 @@ def cases():
     z[::3, :, 0] = 0.0; z[1::3, :, 0] = -0.0; z[::5] = z[::5, :1]
     z[::7, :, 1] = np.float32(1e-6) - np.float32(1e-6)
     out["zeros"] = arrays_of(z)
+    # median fallback on a LARGE node (> 1024 primitives: the device builder's bitonic sort) whose centroids on the split
+    # axis mix -0.0 and +0.0, as Blender-exported OBJs do: the comparator `ca < cb` holds them equal (ties by index), an
+    # order-preserving integer key does not unless the zero is canonicalised. a.x + b.x + c.x is -0 only if all three are.
+    nz = 6000
+    sz = np.zeros((nz, 3, 3), np.float32)
+    yy = (rng.random((nz, 1)) * 0.5).astype(np.float32); zz = (rng.random((nz, 1)) * 0.5).astype(np.float32)
+    sz[:, 0] = [-10, 0, 0]; sz[:, 1] = [10, 0, 0]; sz[:, 2] = [0, 0.01, 0]          # wide slivers: centroid.x = +0 ...
+    sz[:, :, 1] += yy; sz[:, :, 2] += zz
+    pos = np.arange(nz) % 5 >= 2                                                    # ... or a small positive value (60 %)
+    sz[pos, 2, 0] = (np.round(rng.random(int(pos.sum())) * 20 + 1) / 100).astype(np.float32)
+    neg = np.arange(nz) % 5 == 0                                                    # 20 %: triangles in the x = -0 plane
+    sz[neg, :, 0] = np.float32(-0.0)
+    sz[neg, 1, 1] += np.float32(0.3); sz[neg, 2, 2] += np.float32(0.3)
+    out["signed_zero_median"] = arrays_of(sz)
     for n in (1, 2, 3, 5):
         out["tiny%d" % n] = arrays_of(_soup(rng, n, size=0.5, box=1.0))
     return out

@@ -51,6 +51,14 @@ def test_cases_reach_every_branch(oracle):
     assert st["backups"] > 0
     _, _, st = oracle.build_bvh(*CASES["soup5k"], 4)
     assert st["depth"] > 10
+    # signed zeros: the set really holds -0.0 and +0.0 centroids on x, in a node large enough for the device's bitonic sort
+    pts, mesh = CASES["signed_zero_median"]
+    cx = (pts[mesh[:, 0], 0] + pts[mesh[:, 1], 0] + pts[mesh[:, 2], 0]) / np.float32(3.0)
+    assert (np.signbit(cx) & (cx == 0)).sum() > 1000 and (~np.signbit(cx) & (cx == 0)).sum() > 1000
+    on, oi, st = oracle.build_bvh(pts, mesh, 4)
+    zero_ids = np.flatnonzero(cx == 0)
+    where = np.argsort(oi)[zero_ids]                 # positions of the zero-centroid primitives in BVHindices
+    assert np.all(np.diff(where) > 0)                # ... in index order: -0 and +0 were held equal, ties by index
 
 
 def test_device_builder_refuses_without_gpu_or_bad_input(api):
@@ -75,7 +83,7 @@ def test_device_builder_matches_oracle(api, oracle, gpu_ready, name):
         assert np.array_equal(dn, on), (name, leaf)
         assert (dst["n_nodes"], dst["largest_leaf"], dst["backups"], dst["depth"]) == \
                (ost["n_nodes"], ost["largest_leaf"], ost["backups"], ost["depth"])
-        if name.startswith("slivers"):
+        if name.startswith("slivers") or name == "signed_zero_median":
             assert dst["sort_fallbacks"] > 0                      # the median fallback ran on the device
 
 

@@ -51,9 +51,9 @@ def test_camera_rays(api, oracle, gpu_ready):
         assert_bits_equal(g, o, "camera rays")
 
 
-def _scene_pair(api, oracle, cfg):
+def _scene_pair(api, oracle, cfg, options=None):
     hs = api.HostScene(cfg)
-    return api.Scene(hs), hs, oracle.OracleScene(cfg)
+    return api.Scene(hs, options=options), hs, oracle.OracleScene(cfg)
 
 
 def _chain_arrays(api, n=50):
@@ -173,19 +173,18 @@ def test_render_matches_golden(api, gpu_ready, case):
 
 @pytest.mark.parametrize("sched", [("0", "31", "1", "1", "1"), ("4", "3", "2", "1", "1"), ("8", "7", "0", "0", "2"), ("512", "31", "2", "0", "2"),
                                    ("4", "3", "2", "0", "0")])
-def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
+def test_time_sliced_tile_queue(api, gpu_ready, sched):
     """The timed (counters-off) kernels with their scheduling machinery driven hard: tiles are yielded after
     4-8 bounce iterations, queued again and continued by whichever wave is free (production: 512), with and
-    without issue-priority steering, through all three instantiations (LDS-resident; PT_ONCHIP=0: the
-    6-waves-per-SIMD kernel for scenes in HBM, forced by PT_WAVES_HBM=2 although these frames have few tiles;
-    PT_WAVES_HBM=0: the general 4-wave kernel). Scheduling and
+    without issue-priority steering, through all three instantiations (LDS-resident; onchip=0: the
+    6-waves-per-SIMD kernel for scenes in HBM, forced by waves_hbm=2 although these frames have few tiles;
+    waves_hbm=0: the general 4-wave kernel). Scheduling and
     register budget must not reach the image: golden colours bit for bit."""
-    for k, v in zip(("PT_SLICE_ITERS", "PT_SCHED_MASK", "PT_LPT_PRIO", "PT_ONCHIP", "PT_WAVES_HBM"), sched):
-        monkeypatch.setenv(k, v)
+    opts = {k: int(v) for k, v in zip(("slice_iters", "sched_mask", "lpt_prio", "onchip", "waves_hbm"), sched)}
     for case in CASES:
         g = np.load(os.path.join(GOLDEN, case + ".npz"))
         hs = api.HostScene(golden_case_scene(g))
-        sc = api.Scene(hs)
+        sc = api.Scene(hs, options=opts)
         w, h = int(g["w"]), int(g["h"])
         for _ in range(2):                                  # second launch: queue re-initialised
             col, _ = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]))
@@ -200,18 +199,17 @@ def test_time_sliced_tile_queue(api, gpu_ready, monkeypatch, sched):
                                    ("1", "15", "15", "1", "0", "0", "8"),     # 4-wave kernel; traversal and node loop left at the first finished lane
                                    ("1", "4", "1", "15", "2", "0", "0"),      # no time slices
                                    ("2", "4", "8", "8", "1", "1", "4")])      # REFILL also for the LDS-resident instantiation (A/B only)
-def test_loop_exits_and_refill(api, gpu_ready, monkeypatch, knobs):
+def test_loop_exits_and_refill(api, gpu_ready, knobs):
     """pt_trace.h LoopExit / trace_resume: when a wave leaves its node loop, its triangle loop or the traversal
     (lanes that are through go on, the others resume later) is scheduling, not arithmetic — golden colours AND the
     per-pixel work counters bit for bit at every threshold, on all kernels (timed and counting instantiations)."""
-    for k, v in zip(("PT_REFILL", "PT_REFILL_KEEP", "PT_NODE_KEEP", "PT_TRI_KEEP", "PT_WAVES_HBM", "PT_ONCHIP", "PT_SLICE_ITERS"), knobs):
-        monkeypatch.setenv(k, v)
-    monkeypatch.setenv("PT_SCHED_MASK", "3")
+    opts = {k: int(v) for k, v in zip(("refill", "refill_keep", "node_keep", "tri_keep", "waves_hbm", "onchip", "slice_iters"), knobs)}
+    opts["sched_mask"] = 3
     used = []
     for case in CASES:
         g = np.load(os.path.join(GOLDEN, case + ".npz"))
         hs = api.HostScene(golden_case_scene(g))
-        sc = api.Scene(hs)
+        sc = api.Scene(hs, options=opts)
         w, h = int(g["w"]), int(g["h"])
         col, _ = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]), seed=int(g["seed"]))
         assert_bits_equal(col, g["colors"], case)
@@ -225,7 +223,7 @@ def test_loop_exits_and_refill(api, gpu_ready, monkeypatch, knobs):
 
 
 @pytest.mark.parametrize("integrator", [0, 2])
-def test_flat_kernel_and_ties(api, oracle, gpu_ready, scene_dir, monkeypatch, integrator):
+def test_flat_kernel_and_ties(api, oracle, gpu_ready, scene_dir, integrator):
     """pt_trace.h FLAT (scenes with at most 64 nodes / triangles): lockstep node walk + dealt-out triangle tests must
     give the stack walk's image bit for bit — also where two triangles return the SAME t and the reference keeps the
     one it visits first: the tall box exists twice, once diffuse and once as a mirror / as glass."""
@@ -243,12 +241,10 @@ def test_flat_kernel_and_ties(api, oracle, gpu_ready, scene_dir, monkeypatch, in
         col2, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator, counters=True)   # the stack walk
         assert np.array_equal(cnt, ocnt) and not gs.flags()["flat"]
         assert_bits_equal(col2, ocol, cfg)
-        monkeypatch.setenv("PT_FLAT", "0")
-        gs0 = api.Scene(hs)
+        gs0 = api.Scene(hs, options={"flat": 0})
         col3, _ = gs0.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
         assert not gs0.flags()["flat"]
         assert_bits_equal(col3, ocol, cfg)
-        monkeypatch.delenv("PT_FLAT")
 
 
 def test_flat_kernel_single_leaf_scene(api, oracle, gpu_ready):
@@ -288,15 +284,15 @@ def test_render_fresh_scenes_vs_oracle(api, oracle, gpu_ready, scene_dir, integr
 
 @pytest.mark.parametrize("layout", ["queue", "one_tile_per_wave", "xcd_bands"])
 @pytest.mark.parametrize("integrator", [0, 2])
-def test_render_hand_built_deep_tree(api, oracle, gpu_ready, monkeypatch, integrator, layout):
+def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator, layout):
     """Array-level boundary + a tree deeper than the LDS stack, through the full render loop — in the 12-wave
     workgroups of the kernel for scenes in HBM (shared scene cache, per-wave spill areas), fed by the tile queue,
-    one tile per wave (PT_PERSISTENT=0) or in per-XCD bands."""
-    monkeypatch.setenv("PT_WAVES_HBM", "2")              # the 6-wave kernel also for this 6-tile frame
-    if layout == "one_tile_per_wave": monkeypatch.setenv("PT_PERSISTENT", "0")
-    if layout == "xcd_bands": monkeypatch.setenv("PT_XCD_BANDS", "1")
+    one tile per wave (persistent=0) or in per-XCD bands."""
+    opts = {"waves_hbm": 2}                              # the 6-wave kernel also for this 6-tile frame
+    if layout == "one_tile_per_wave": opts["persistent"] = 0
+    if layout == "xcd_bands": opts["xcd_bands"] = 1
     arr = _chain_arrays(api)
-    gs, osc = api.Scene.from_arrays(arr), oracle.OracleScene(arrays=arr)
+    gs, osc = api.Scene.from_arrays(arr, options=opts), oracle.OracleScene(arrays=arr)
     cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
     col, cnt = gs.render(cam, 24, 16, 4, 5, integrator=integrator, counters=True)
     ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), width=24, height=16, spp=4, max_depth=5, integrator=integrator, counters=True)
@@ -492,20 +488,20 @@ def test_fuzz_scenes(api, oracle, gpu_ready, scene_dir, seed):
         assert_bits_equal(wf, ocol, "fuzz %d, wavefront" % seed)
 
 
-def test_opt_in_culling(api, gpu_ready, scene_dir, monkeypatch):
+def test_opt_in_culling(api, gpu_ready, scene_dir):
     """pt_set_culling is NOT the reference's visiting set (pt_api.h) and is off by default: at full scale it changes
     about 3 pixels per 1e9 rays (tools/cull_experiment.py). What this test pins is the plumbing: at the scale of the
     golden scenes, eight random scenes and a small frame of the 263 k-triangle atrium the image is the same bit for
     bit while fewer boxes are tested. Forced onto the kernel for scenes in HBM (the only one with the instantiation)."""
     from cudapathtracer_amd import scenes
-    monkeypatch.setenv("PT_ONCHIP", "0"); monkeypatch.setenv("PT_WAVES_HBM", "2")
+    opts = {"onchip": 0, "waves_hbm": 2}
     cfgs = [golden_case_scene(np.load(os.path.join(GOLDEN, c + ".npz"))) for c in CASES]
     cfgs += [scenes.fuzz(os.path.join(scene_dir, "cfuzz%d" % k), k)["config"] for k in range(8)]
     cfgs.append(scenes.atrium(os.path.join(scene_dir, "catrium"), 96, 54, 4, 8, name="catrium")["config"])
     fewer = 0
     for cfg in cfgs:
         hs = api.HostScene(cfg)
-        sc = api.Scene(hs)
+        sc = api.Scene(hs, options=opts)
         i = hs.info
         exact, ce = sc.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], counters=True)
         assert not sc.flags()["culling"]
@@ -534,7 +530,7 @@ def test_thin_lens_camera_render(api, oracle, gpu_ready, scene_dir):
     assert_bits_equal(col, ocol, "thin-lens render")
 
 
-def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir, monkeypatch):
+def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir):
     """1920x1080 Cornell, 48 spp: the frame from one-tile-per-wave workgroups (no queue at all) against the
     persistent kernel forced to yield every 32 iterations — some 300 000 hand-overs of tile state between waves
     on all eight XCDs — and against the production setting. Bit for bit, twice (no run-to-run variation)."""
@@ -542,12 +538,8 @@ def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir, monkeypatch
     cfg = scenes.cornell(os.path.join(scene_dir, "c2s"), 1920, 1080, 48, 8, name="c2s")["config"]
     hs = api.HostScene(cfg)
     frames = []
-    for env in ({"PT_PERSISTENT": "0"}, {"PT_SLICE_ITERS": "32", "PT_SCHED_MASK": "7"}, {}, {"PT_SLICE_ITERS": "32", "PT_SCHED_MASK": "7", "PT_ONCHIP": "0", "PT_WAVES_HBM": "2"}):
-        for k in ("PT_PERSISTENT", "PT_SLICE_ITERS", "PT_SCHED_MASK", "PT_ONCHIP", "PT_WAVES_HBM"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        sc = api.Scene(hs)
+    for env in ({"persistent": 0}, {"slice_iters": 32, "sched_mask": 7}, {}, {"slice_iters": 32, "sched_mask": 7, "onchip": 0, "waves_hbm": 2}):
+        sc = api.Scene(hs, options=env)
         a, _ = sc.render(hs.camera(), 1920, 1080, 48, 8)
         b, _ = sc.render(hs.camera(), 1920, 1080, 48, 8)
         assert sc.last_kernel_ms() > 0.0
@@ -558,7 +550,7 @@ def test_full_frame_scheduling_invariance(api, gpu_ready, scene_dir, monkeypatch
         assert_bits_equal(f, frames[0], "scheduling reached the image")
 
 
-def test_full_frame_kernels_agree_on_a_scene_in_hbm(api, gpu_ready, scene_dir, monkeypatch):
+def test_full_frame_kernels_agree_on_a_scene_in_hbm(api, gpu_ready, scene_dir):
     """BASELINE C3's geometry class (82 k triangles, tree in HBM) at 1920x1080, 3 spp, depth 6: the image must not depend
     on which instantiation rendered it — the production kernel (12-wave workgroups, loop exits, resumable traversal),
     the same with plain loops and the shadow ray inside the bounce, the 4-wave kernel, the counting kernel, the
@@ -567,19 +559,14 @@ def test_full_frame_kernels_agree_on_a_scene_in_hbm(api, gpu_ready, scene_dir, m
     cfg = scenes.blob_in_box(os.path.join(scene_dir, "b82"), 1920, 1080, 3, 6, name="b82")["config"]
     hs = api.HostScene(cfg)
     assert hs.info["n_tris"] > 80000
-    knobs = ("PT_REFILL", "PT_NODE_KEEP", "PT_TRI_KEEP", "PT_WAVES_HBM", "PT_SLICE_ITERS", "PT_PERSISTENT")
     frames = []
-    for env in ({}, {"PT_REFILL": "0", "PT_NODE_KEEP": "0", "PT_TRI_KEEP": "0"}, {"PT_WAVES_HBM": "0"}, {"PT_REFILL": "1", "PT_REFILL_KEEP": "12", "PT_SLICE_ITERS": "64"},
-                {"PT_PERSISTENT": "0"}):
-        for k in knobs + ("PT_REFILL_KEEP",):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        sc = api.Scene(hs)
+    for env in ({}, {"refill": 0, "node_keep": 0, "tri_keep": 0}, {"waves_hbm": 0}, {"refill": 1, "refill_keep": 12, "slice_iters": 64},
+                {"persistent": 0}):
+        sc = api.Scene(hs, options=env)
         a, _ = sc.render(hs.camera(), 1920, 1080, 3, 6)
         fl = sc.flags()
         assert not fl["onchip"] and not fl["flat"]
-        assert fl["refill"] == (env.get("PT_REFILL", "1") != "0") and fl["hbm_kernel"] == (env.get("PT_WAVES_HBM", "1") != "0"), (env, fl)
+        assert fl["refill"] == (env.get("refill", 1) != 0) and fl["hbm_kernel"] == (env.get("waves_hbm", 1) != 0), (env, fl)
         frames.append(a)
         if not env:
             b, cnt = sc.render(hs.camera(), 1920, 1080, 3, 6, counters=True)          # counting kernel
@@ -617,3 +604,25 @@ def test_full_size_properties(api, gpu_ready, scene_dir):
     assert ca[..., 0].min() >= 2                                             # every pixel traced its 2 camera rays
     m = np.nanmean(a[..., :3]) / 2
     assert 0.05 < m < 5.0
+
+
+def test_options_api(api, gpu_ready):
+    """pt_set_option / pt_get_option: the explicit replacement of round 1's environment switches. Unknown names and
+    values out of range are errors; a scene starts from the documented defaults whatever the process environment holds."""
+    os.environ["PT_FLAT"] = "0"; os.environ["PT_CULL"] = "1"; os.environ["PT_ONCHIP"] = "0"     # must be ignored
+    try:
+        hs = api.HostScene(golden_scene("cornell32"))
+        sc = api.Scene(hs)
+    finally:
+        for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
+            del os.environ[k]
+    defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0}
+    assert {k: sc.get_option(k) for k in defaults} == defaults
+    sc.render(hs.camera(), 32, 32, 1, 4)
+    assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
+    for name, bad in (("no_such_option", 1), ("sched_mask", 6), ("node_keep", 16), ("waves_hbm", 3), ("flat", -1)):
+        with pytest.raises(api.PtError):
+            sc.set_option(name, bad)
+    sc.set_options({"flat": 0, "sched_mask": 7, "waves_hbm": 2})
+    assert (sc.get_option("flat"), sc.get_option("sched_mask"), sc.get_option("waves_hbm")) == (0, 7, 2)
