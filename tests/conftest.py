@@ -38,6 +38,26 @@ def scene_dir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("scenes"))
 
 
+def golden_cases():
+    """Names of the small full-frame fixtures (tests/golden/*.npz without the window_* files)."""
+    import glob
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("window_"))
+
+
+def window_cases():
+    """Names of the window fixtures: 64x64 windows of the real BASELINE scenes at the 1080p camera."""
+    import glob
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "window_*.npz")))
+
+
+def window_scene(g, outdir):
+    """Regenerate the scene of a window fixture from scenes.py and check it is the scene the fixture was made from."""
+    from cudapathtracer_amd import scenes
+    s = getattr(scenes, str(g["generator"]))(outdir, width=int(g["w"]), height=int(g["h"]), spp=int(g["spp"]), max_depth=int(g["max_depth"]),
+                                              name=os.path.basename(outdir))
+    return s
+
+
 def golden_scene(name, sub="scenes"):
     return os.path.join(GOLDEN, sub, name + ".rendertron")
 

@@ -4,13 +4,14 @@ Bar (BASELINE.json north_star): integer indices / counters bit-exact; radiance w
 relative. Because both sides implement one fixed arithmetic the radiance is in fact
 compared BIT-EXACTLY here; the 1e-4 tolerance is asserted separately as the contractual bound.
 """
+import ctypes
 import glob
 import os
 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_case_scene, golden_scene
+from conftest import GOLDEN, golden_case_scene, golden_cases, golden_scene, window_cases, window_scene
 from util import assert_bits_equal, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -153,7 +154,7 @@ def test_bsdf_probes(api, oracle, gpu_ready):
     assert_bits_equal(g, o, "f_eval / pdf_eval")
 
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = golden_cases()
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -626,3 +627,71 @@ def test_options_api(api, gpu_ready):
             sc.set_option(name, bad)
     sc.set_options({"flat": 0, "sched_mask": 7, "waves_hbm": 2})
     assert (sc.get_option("flat"), sc.get_option("sched_mask"), sc.get_option("waves_hbm")) == (0, 7, 2)
+
+
+def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
+    """A 64x64 window = 8 runs of 8 consecutive tiles (pt_tile_range is an arithmetic progression of tile ids)."""
+    x0, y0, x1, y1 = (int(v) for v in rect)
+    tiles_x = (w + 7) // 8
+    col = np.zeros((h, w, 4), np.float32)
+    cnt = np.zeros((h, w, 8), np.uint32) if counters else None
+    for ty in range(y0 // 8, y1 // 8):
+        tr = api.TileRange(ty * tiles_x + x0 // 8, 1, (x1 - x0) // 8)
+        if counters:
+            rc = api.lib().pt_render_counted(sc.h, ctypes.byref(cam), w, h, spp, md, 0, 1, api.SEED, ctypes.byref(tr), col.ctypes.data_as(ctypes.c_void_p),
+                                             cnt.ctypes.data_as(ctypes.c_void_p))
+            assert rc == 0, api.lib().pt_last_error()
+        else:
+            sc.render(cam, w, h, spp, md, tiles=tr, out=col)
+    return col[y0:y1, x0:x1], (cnt[y0:y1, x0:x1] if counters else None)
+
+
+@pytest.mark.parametrize("mode", ["production", "plain_loops_4wave", "counted", "wavefront"])
+@pytest.mark.parametrize("case", window_cases())
+def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, mode):
+    """BASELINE C3 / C4 / C5 geometry and depth at the 1080p camera, against the oracle: 64x64 windows of the 82 k-triangle
+    scene (depth 8) and of the 263 k-triangle atrium (depth 16: BVHSceneIntersect stacks 27 deep, Russian roulette after 16
+    bounces, paths of up to 100 iterations) — the production kernel for scenes in HBM (12-wave workgroups, loop exits,
+    REFILL; forced although a window has few tiles), the 4-wave kernel with plain loops, the counting kernel (all eight
+    per-pixel counters) and the wavefront variant (C5). Committed fixture AND a live oracle run of the first window."""
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    s = window_scene(g, os.path.join(scene_dir, case))
+    assert s["sha256"] == str(g["scene_sha256"])
+    hs = api.HostScene(s["config"])
+    w, h, spp, md = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"])
+    opts = {"production": {"waves_hbm": 2}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
+            "counted": {"waves_hbm": 2}, "wavefront": {}}[mode]
+    sc = api.Scene(hs, options=opts)
+    if mode == "wavefront":
+        sc.set_variant("wavefront")
+    cam = hs.camera()
+    for k, rect in enumerate(g["rects"]):
+        col, cnt = _render_window(api, sc, cam, w, h, spp, md, rect, counters=(mode == "counted"))
+        assert_bits_equal(col, g["colors"][k], "%s window %d (%s)" % (case, k, mode))
+        if mode == "counted":
+            assert np.array_equal(cnt, g["counters"][k]), (case, k)
+        if mode == "production":
+            fl = sc.flags()
+            assert fl["hbm_kernel"] and fl["refill"] and not fl["onchip"] and not fl["culling"], fl
+    x0, y0, x1, y1 = (int(v) for v in g["rects"][1])
+    ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8)
+    assert_bits_equal(ocol[y0:y1, x0:x1], g["colors"][1], "fixture == live oracle")
+    assert np.array_equal(ocnt[y0:y1, x0:x1], g["counters"][1])
+
+
+def test_fuzz_scene_depth16(api, oracle, gpu_ready, scene_dir):
+    """A random scene over the whole material table at the C4 depth: Russian roulette only after 16 bounces."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.fuzz(os.path.join(scene_dir, "fuzzd16"), 101, width=24, height=16, spp=4, max_depth=16, name="fuzzd16")["config"]
+    for opts in ({}, {"onchip": 0, "waves_hbm": 2}):
+        gs, hs, osc = _scene_pair(api, oracle, cfg, options=opts)
+        i = hs.info
+        assert i["max_depth"] == 16
+        for integ in (0, 2):
+            ocol, ocnt, _ = osc.render(integrator=integ, counters=True, threads=8)
+            col, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ, counters=True)
+            assert np.array_equal(cnt, ocnt), integ
+            assert_bits_equal(col, ocol, "fuzz depth 16, integrator %d" % integ)
+            timed, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ)
+            assert_bits_equal(timed, ocol, "fuzz depth 16, integrator %d, timed kernel" % integ)
+        assert int(ocnt[..., 7].max()) > 16

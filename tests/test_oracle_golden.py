@@ -5,10 +5,10 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_case_scene, golden_scene
+from conftest import GOLDEN, golden_case_scene, golden_cases, golden_scene, window_cases, window_scene
 from util import assert_bits_equal
 
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = golden_cases()
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -73,3 +73,20 @@ def test_baseline_config0_host_loop(oracle, scene_dir):
     assert int(ca[..., 0].sum()) == 4720774                                   # closest-hit rays of the frame
     assert hashlib.sha256(a.tobytes()).hexdigest() == "615b8397923e2b526aa64713ad524803550a64fb0f741e40b09348a2f8e73927"
     assert hashlib.sha256(ca.tobytes()).hexdigest() == "de43006ee22d1cbab2f3e305d5d450501b05f6458da2a0757b45355193e0e23c"
+
+
+@pytest.mark.parametrize("case", window_cases())
+def test_oracle_reproduces_window_fixtures(oracle, scene_dir, case):
+    """64x64 windows of the real BASELINE scenes (82 k triangles at depth 8; 263 k triangles at depth 16) at the 1080p
+    camera: the regenerated scene is the one the fixture was made from, and the oracle's `rect` render reproduces it."""
+    g = np.load(os.path.join(GOLDEN, case + ".npz"))
+    s = window_scene(g, os.path.join(scene_dir, case))
+    assert s["sha256"] == str(g["scene_sha256"]), "scenes.py no longer generates the scene this fixture pins"
+    sc = oracle.OracleScene(s["config"])
+    assert sc.info["n_tris"] == int(g["n_tris"]) > 80000
+    for k, (x0, y0, x1, y1) in enumerate(g["rects"]):
+        col, cnt, _ = sc.render(rect=(int(x0), int(y0), int(x1), int(y1)), counters=True, threads=8)
+        assert_bits_equal(col[y0:y1, x0:x1], g["colors"][k], "%s window %d" % (case, k))
+        assert np.array_equal(cnt[y0:y1, x0:x1], g["counters"][k])
+    if "atrium" in case:
+        assert int(g["max_depth"]) == 16 and int(g["counters"][..., 7].max()) > 64      # paths long past the roulette depth
