@@ -177,6 +177,14 @@ def save_bmp(path, rgba, post_process=True):
         raise PtError("could not write " + path)
 
 
+def save_csv_mono(path, rgba, channel=0):
+    """Image::saveImageCSV_MONO(channel) (imageUtil.cu:123-142)."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    if lib().novum_save_csv_mono(path.encode(), _p(rgba), w, h, int(channel)) != 0:
+        raise PtError("could not write " + path)
+
+
 def init_render(config_path, render_number=0, base_dir=None, bmp_path=None, preview_bmp=None, preview_csv=None,
                 interval_seconds=5.0, chunk_spp=0):
     """initRender (main.cu:235-923) for the unidirectional integrators; returns finalised [h,w,4].

@@ -471,6 +471,9 @@ bool load_bmp(const std::string& file, std::vector<pt_float4>& px, int& w, int& 
 // ---- image output (imageUtil.cu:69-100, 202-232) --------------------------------------------------
 float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 float aces(float c) { return clamp01((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f)); }
+// imageUtil.cu:90-92: static_cast<unsigned char>(clamp(c, 0, 1) * 255.0f + 0.5f). A NaN passes the clamp and the cast is
+// undefined; x86 builds of the reference produce 0 (cvttss2si's 0x80000000, low byte) — fixed as 0 here.
+unsigned char to_byte(float c) { const float v = clamp01(c) * 255.0f + 0.5f; return v != v ? (unsigned char)0 : (unsigned char)v; }
 
 }  // namespace
 
@@ -633,9 +636,9 @@ int novum_save_bmp(const char* path, const float* rgba, int w, int h, int post) 
             const float* p = rgba + 4 * ((size_t)y * w + x);
             float r = p[0], g = p[1], b = p[2];
             if (post) { r = powf(aces(r), ig); g = powf(aces(g), ig); b = powf(aces(b), ig); }      // toneMap + gammaCorrect
-            line[x * 3 + 0] = (unsigned char)(clamp01(b) * 255.0f + 0.5f);
-            line[x * 3 + 1] = (unsigned char)(clamp01(g) * 255.0f + 0.5f);
-            line[x * 3 + 2] = (unsigned char)(clamp01(r) * 255.0f + 0.5f);
+            line[x * 3 + 0] = to_byte(b);
+            line[x * 3 + 1] = to_byte(g);
+            line[x * 3 + 2] = to_byte(r);
         }
         fwrite(line.data(), 1, row, f);
     }

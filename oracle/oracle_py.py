@@ -52,6 +52,9 @@ def lib():
         L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_finalise.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_save_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_save_csv_mono.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.oracle_tonemap_gamma.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_xorwow_init.argtypes = [C.c_ulonglong, C.c_uint, C.c_void_p]
         L.oracle_xorwow_next.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_xorwow_uniform.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -197,6 +200,30 @@ def finalise(colors, spp):
     c = np.ascontiguousarray(colors, np.float32).copy()
     lib().oracle_finalise(_p(c), c.size // 4, spp)
     return c
+
+
+def save_bmp(path, rgba, post_process=True):
+    """Image::saveImageBMP (imageUtil.cu:69-100) on a [h,w,4] float32 frame, y = 0 bottom."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    if lib().oracle_save_bmp(path.encode(), _p(rgba), w, h, int(post_process)) != 0:
+        raise RuntimeError("oracle: could not write " + path)
+
+
+def save_csv_mono(path, rgba, channel=0):
+    """Image::saveImageCSV_MONO (imageUtil.cu:123-142)."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    if lib().oracle_save_csv_mono(path.encode(), _p(rgba), w, h, int(channel)) != 0:
+        raise RuntimeError("oracle: could not write " + path)
+
+
+def tonemap_gamma(rgba):
+    """gammaCorrect(toneMap(.)) per pixel (imageUtil.cu:202-222)."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    out = np.zeros_like(rgba)
+    lib().oracle_tonemap_gamma(_p(rgba), rgba.size // 4, _p(out))
+    return out
 
 
 def xorwow_init(seed, subseq):

@@ -402,9 +402,24 @@ def test_init_render_with_preview_files(api, oracle, gpu_ready, tmp_path):
     bmp, pbmp, pcsv = str(tmp_path / "final.bmp"), str(tmp_path / "render.bmp"), str(tmp_path / "renderCSV.csv")
     img = api.init_render(golden_case_scene(g), bmp_path=bmp, preview_bmp=pbmp, preview_csv=pcsv, interval_seconds=0.0, chunk_spp=4)
     assert_bits_equal(img, oracle.finalise(g["colors"], 8).reshape(32, 32, 4), "init_render with previews")
-    for f in (bmp, pbmp):
+    ref_bmp = str(tmp_path / "oracle.bmp")
+    oracle.save_bmp(ref_bmp, oracle.finalise(g["colors"], 8).reshape(32, 32, 4), post_process=True)     # config says "Post Process: true"
+    for f in (bmp, pbmp):                                                   # the last preview holds all 8 samples
         b = open(f, "rb").read()
         assert b[:2] == b"BM" and len(b) == 54 + 32 * 32 * 3 and int.from_bytes(b[18:22], "little") == 32
+        assert b == open(ref_bmp, "rb").read(), "BMP bytes differ from the oracle's saveImageBMP"
+    ref_csv = str(tmp_path / "oracle.csv")
+    oracle.save_csv_mono(ref_csv, oracle.finalise(g["colors"], 8).reshape(32, 32, 4), 0)
+    assert open(pcsv, "rb").read() == open(ref_csv, "rb").read()
+    # "Post Process: false" (objects.cuh:844-943 key): the writer skips toneMap / gammaCorrect
+    cfg2 = str(tmp_path / "nopost.rendertron")
+    src = golden_case_scene(g)
+    open(cfg2, "w").write(open(src).read().replace("Post Process: true", "Post Process: false"))
+    bmp2 = str(tmp_path / "nopost.bmp")
+    img2 = api.init_render(cfg2, base_dir=os.path.dirname(src), bmp_path=bmp2)
+    assert_bits_equal(img2, img, "post-processing must not touch the returned radiance")
+    oracle.save_bmp(ref_bmp, img2, post_process=False)
+    assert open(bmp2, "rb").read() == open(ref_bmp, "rb").read()
     rows = open(pcsv).read().strip().split("\n")
     assert len(rows) == 32 and len(rows[0].split(",")) == 32 and "e" in rows[0].split(",")[0]
     # last preview = all 8 samples: CSV row 0 is image row y = 0 (bottom), channel 0, 3 significant decimals
