@@ -117,6 +117,13 @@ def lib():
     L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
     L.pt_get_option.argtypes = [vp, C.c_char_p, vp]
     L.pt_debug_stamps.argtypes = [vp, vp]
+    L.pt_rank_tiles.argtypes = [i32, i32, i32, i32, C.POINTER(TileRange)]
+    L.pt_multi_create.restype = vp; L.pt_multi_create.argtypes = [C.POINTER(SceneDesc), i32, vp]
+    L.pt_multi_destroy.argtypes = [vp]
+    L.pt_multi_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.pt_multi_set_variant.argtypes = [vp, i32]
+    L.pt_multi_render.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, vp, vp]
+    L.pt_render_multi.argtypes = [C.POINTER(SceneDesc), i32, vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     L.pt_probe_camera_rays.argtypes = [C.POINTER(Camera), u64, i32, vp, vp]
@@ -468,6 +475,61 @@ class Scene:
         return out
 
 
+MULTI_STATS = np.dtype([("n_devices", "i4"), ("gather", "i4"), ("kernel_ms", "f4", (16,)), ("render_ms", "f4"), ("gather_ms", "f4"), ("total_ms", "f4")])
+
+
+class MultiScene:
+    """pt_multi: one replica of the scene per HIP device, frame sharded by interleaved 8x8 tiles, one gather to device 0
+    (include/pt_api.h, "multi-GPU"). device_ids=None means devices 0 .. n_devices-1."""
+
+    def __init__(self, host: "HostScene", n_devices, device_ids=None, options=None):
+        ids = np.ascontiguousarray(device_ids, np.int32) if device_ids is not None else None
+        self._keep = host
+        self.h = lib().pt_multi_create(C.byref(host.desc), int(n_devices), _p(ids))
+        if not self.h:
+            raise PtError("pt_multi_create failed: " + lib().pt_last_error().decode(errors="replace"))
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+        self.stats = None
+
+    def set_option(self, name, value):
+        _check(lib().pt_multi_set_option(self.h, name.encode(), int(value)), "pt_multi_set_option(%s)" % name)
+        return self
+
+    def set_variant(self, variant):
+        _check(lib().pt_multi_set_variant(self.h, int({"megakernel": 0, "wavefront": 1}.get(variant, variant))), "pt_multi_set_variant")
+        return self
+
+    def render(self, camera, w, h, spp, max_depth, integrator=UNIDIRECTIONAL, use_mis=True, seed=SEED, out=None):
+        col = np.zeros((h, w, 4), np.float32) if out is None else out
+        st = np.zeros(1, MULTI_STATS)
+        _check(lib().pt_multi_render(self.h, C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, _p(col), _p(st)), "pt_multi_render")
+        self.stats = {"n_devices": int(st[0]["n_devices"]), "gather": {0: "none", 1: "rccl", 2: "peer_copy"}[int(st[0]["gather"])],
+                      "kernel_ms": [float(v) for v in st[0]["kernel_ms"][:int(st[0]["n_devices"])]],
+                      "render_ms": float(st[0]["render_ms"]), "gather_ms": float(st[0]["gather_ms"]), "total_ms": float(st[0]["total_ms"])}
+        return col
+
+    def close(self):
+        if self.h:
+            lib().pt_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_multi(host, n_devices, camera, w, h, spp, max_depth, integrator=UNIDIRECTIONAL, use_mis=True, seed=SEED, device_ids=None):
+    """pt_render_multi: the one-shot form."""
+    ids = np.ascontiguousarray(device_ids, np.int32) if device_ids is not None else None
+    col = np.zeros((h, w, 4), np.float32)
+    _check(lib().pt_render_multi(C.byref(host.desc), int(n_devices), _p(ids), C.byref(camera), w, h, spp, max_depth, integrator, int(use_mis), seed, _p(col), None),
+           "pt_render_multi")
+    return col
+
+
 def parse_options(pairs):
     """["flat=0", "waves_hbm=2"] -> {"flat": 0, "waves_hbm": 2} for the --opt flag of bench.py and tools/."""
     out = {}
@@ -492,10 +554,10 @@ def n_tiles(w, h):
 
 
 def rank_tiles(w, h, rank, world):
-    """Interleaved tile ownership: rank r renders tiles {t : t mod world == r}."""
-    total = n_tiles(w, h)
-    count = (total - rank + world - 1) // world if rank < total else 0
-    return TileRange(rank, world, count)
+    """Interleaved tile ownership: rank r renders tiles {t : t mod world == r} (pt_rank_tiles)."""
+    tr = TileRange()
+    lib().pt_rank_tiles(w, h, rank, world, C.byref(tr))
+    return tr
 
 
 def probe_rng(subsequences, n_draws, seed=SEED):

@@ -215,6 +215,37 @@ int pt_get_option(pt_scene* scene, const char* name, int* value);
  * triangle loop of the closest-hit traversal, then of the shadow traversal (tools/lane_util.py). */
 int pt_debug_stamps(pt_scene* scene, unsigned long long* out8);
 
+/* ---- multi-GPU: the framebuffer sharded by screen tile over the GPUs of one node -------------
+ * The reference is single-GPU (one launch_unidirectional per frame, main.cu:565). A pixel depends only on (scene,
+ * camera, global pixel index, seed), so device r of N renders the 8x8 tiles {t : t mod N == r} of a replicated scene
+ * — no data-path collective — and ONE gather (RCCL send/recv over xGMI, or hipMemcpyPeerAsync) brings the tile
+ * buffers to device 0, which de-interleaves them. One host thread per device inside the call; blocking; the result
+ * is bit-identical to pt_render for any N. This is what a C++ host (the reference's main.cu) binds to use 8 GPUs. */
+#define PT_MULTI_MAX_DEVICES 16
+typedef struct pt_multi pt_multi;          /* opaque: one scene replica, stream and communicator per device */
+typedef struct pt_multi_stats {
+    int32_t n_devices;
+    int32_t gather;                        /* transport the gather used: 0 none (one device), 1 RCCL, 2 peer copies */
+    float kernel_ms[PT_MULTI_MAX_DEVICES]; /* per device: its megakernel, HIP events on its stream */
+    float render_ms, gather_ms, total_ms;  /* host wall clock: upload + render (max over devices), gather, whole call */
+} pt_multi_stats;
+/* Tile ownership of `rank` among `world` devices (interleaved). */
+void pt_rank_tiles(int w, int h, int rank, int world, pt_tile_range* out);
+/* Replicates the scene on n_devices HIP devices (device_ids NULL = 0 .. n_devices-1). NULL on error. */
+pt_multi* pt_multi_create(const pt_scene_desc* desc, int n_devices, const int* device_ids);
+void pt_multi_destroy(pt_multi* m);
+/* "gather": 0 auto (RCCL, else peer copies), 1 RCCL, 2 hipMemcpyPeerAsync; "self_gather" 1: with ONE device, still send
+ * the tile buffer through the collective (to itself) — a plumbing check for one-GPU machines; any pt_set_option name:
+ * applied to every replica. */
+int pt_multi_set_option(pt_multi* m, const char* name, int value);
+int pt_multi_set_variant(pt_multi* m, int variant);
+/* pt_render over all devices of `m`: host buffer in / out with `+=` semantics like pt_render. stats may be NULL. */
+int pt_multi_render(pt_multi* m, const pt_camera* camera, int w, int h, int spp, int max_depth, int integrator, int use_mis,
+                    uint64_t seed, float* out_rgba_sum, pt_multi_stats* stats);
+/* One-shot form: create, render, destroy. */
+int pt_render_multi(const pt_scene_desc* desc, int n_devices, const int* device_ids, const pt_camera* camera, int w, int h, int spp,
+                    int max_depth, int integrator, int use_mis, uint64_t seed, float* out_rgba_sum, pt_multi_stats* stats);
+
 /* ---- probes: single stages of the path on the GPU, for known-answer tests -------------- */
 int pt_probe_rng(uint64_t seed, int n, const uint32_t* subsequences, int n_draws, uint32_t* out_state6, uint32_t* out_u32, float* out_uniform);
 int pt_probe_math(int n, const float* x, float* out_sin, float* out_cos, float* out_exp, float* out_rsqrt, float* out_pow5);
