@@ -12,10 +12,14 @@ de-interleaves them; that gather + de-interleave is inside the timed region.
 
 Rank 0 prints ONE JSON line. `value` is whole-job Mray/s (closest-hit + shadow traversals, all
 ranks) with the scene resident in HBM when the clock starts. Ray / box / triangle counts come from
-a counted, untimed pass of the identical (deterministic) workload. `roofline` prices the megakernel
-against the 8 TB/s HBM peak with SURVEY.md §8(d)'s ALGORITHMIC bytes and the kernel's own duration
-from HIP events on its launch stream. `cpu_baseline` is the CPU oracle on a bounded sample of the
-same workload (rank 0, N = 1 only) — a reported reference point, not the target.
+a counted, untimed pass of the identical (deterministic) workload, and the timed frame must equal
+the counted frame bit for bit (`frame_sha`; the run fails otherwise). `roofline` prices the
+megakernel against the bound that binds it (tools/roofline.py): VALU issue slots for scenes that
+live in LDS (the headline), the L1's cache-line rate for scenes in HBM — both fractions are <= 1 by
+construction; SURVEY.md §8(d)'s algorithmic bytes are kept as the labelled field `algorithmic`.
+`secondary` (N = 1) holds the same measurement for BASELINE C3 at its full sample count and for the
+C4 scene at 32 of its 4096 spp (one timed step each). `cpu_baseline` is the CPU oracle on a bounded
+sample of the headline workload (rank 0, N = 1 only) — a reported reference point, not the target.
 """
 import argparse
 import json
@@ -26,10 +30,15 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+
+import hashlib  # noqa: E402
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+import roofline as RF  # noqa: E402  (tools/roofline.py: every roofline number of the line below is computed there)
 
 WORKLOADS = {
     # name: (generator, kwargs)  — C2 is the headline; C3/C4 are selectable for profiling
@@ -37,12 +46,6 @@ WORKLOADS = {
     "blob82k_1920x1080_1024spp_depth8_mis": ("blob_in_box", dict(width=1920, height=1080, spp=1024, max_depth=8)),
     "atrium262k_1920x1080_4096spp_depth16_mis": ("atrium", dict(width=1920, height=1080, spp=4096, max_depth=16)),
 }
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-
-
-def alg_bytes(c, n_px):
-    """32 B/box test, 16 B/node pop, 52 B/triangle test, 96 B/accepted hit, 16 B/pixel."""
-    return 32 * c["box_tests"] + 16 * c["node_pops"] + 52 * c["tri_tests"] + 96 * c["hits"] + 16 * n_px
 
 
 def host_threads():
@@ -78,16 +81,127 @@ def _tf(b):
     return "true" if b else "false"
 
 
-def pmc_traffic(workload, spp):
-    """HBM bytes per megakernel launch from the committed rocprofv3 PMC passes (profiles/), if they
-    were taken on this workload; None otherwise. bench.py cannot run the profiler on itself."""
-    try:
-        for t in json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["entries"]:
-            if t.get("workload") == workload and t.get("spp") == spp:
-                return t["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+def kernel_name(flags, variant):
+    if variant != "megakernel":
+        return "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)"
+    if flags["hbm_kernel"]:
+        return "pt::megakernel_hbm<0, false, %s, %s>" % (_tf(flags["culling"]), _tf(flags["refill"]))
+    return "pt::megakernel<0, false, false, %s, %s, %s>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))
+
+
+def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
+    """One workload: scene into HBM, counted pass, `steps` timed passes, frame check. Returns the result dict on rank 0."""
+    from cudapathtracer_amd import api, scenes
+    from cudapathtracer_amd import distributed as D
+    rank, world, red_dev, share = ctx["rank"], ctx["world"], ctx["red_dev"], ctx["share"]
+    gen, kw = WORKLOADS[workload]
+    tmp = tempfile.mkdtemp(prefix="ptbench_r%d_" % rank)
+    sinfo = getattr(scenes, gen)(tmp, **kw)
+    host = api.HostScene(sinfo["config"])
+    info = host.info
+    w, h, md = info["width"], info["height"], info["max_depth"]
+    spp = spp_override or info["spp"]
+    cam = host.camera()
+    scene = api.Scene(host, options=opts).set_variant(variant)           # scene resident in HBM from here on
+    if culling:
+        scene.set_culling(True)
+
+    tr = api.rank_tiles(w, h, rank, world)
+    pad = D.padded_tile_count(w, h, world)
+    tiles = torch.zeros(pad, 64, 4, device="cuda")
+    frame = torch.zeros(h, w, 4, device="cuda") if rank == 0 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(count_work=False):
+        tiles.zero_()                                           # out_colors starts at 0 (main.cu:339)
+        scene.render_tiles_device(cam, w, h, spp, md, tiles.data_ptr(), tiles=tr, count_work=count_work, stream=stream)
+        gathered = D.gather_tiles(tiles, w, h, rank, world)     # the path's single collective (N > 1)
+        if rank == 0:
+            D.assemble_device(gathered, w, h, world, frame, stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def frame_sha():
+        if rank != 0:
+            return None
+        f = frame.cpu().numpy().copy()
+        f[np.isnan(f)] = np.float32(np.nan)                      # one NaN bit pattern (a NaN's payload is not part of the image)
+        return hashlib.sha256(f.tobytes()).hexdigest()
+
+    # counted pass (untimed): deterministic workload => these counts are exactly the timed steps' counts
+    scene.reset_counters()
+    step(count_work=True)
+    fence()
+    scene.last_kernel_ms()                                       # raises if the counted launch did not complete its frame
+    sha_counted = frame_sha()
+    cnt = scene.counters()
+    gnodes = scene.global_node_fetches() if variant == "megakernel" else 0
+    cvec = torch.tensor([cnt[k] for k in api.COUNTER_KEYS], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(cvec)
+    total = dict(zip(api.COUNTER_KEYS, (int(v) for v in cvec.tolist())))
+
+    for _ in range(max(0, warmup - 1)):                          # the counted pass is the first warm-up
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-launch megakernel time from HIP events on its stream (last launch; all launches are identical);
+    # raises if the tile queue reported an incomplete frame
+    kernel_ms = scene.last_kernel_ms()
+    sha_timed = frame_sha()
+    et = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+    elapsed, _ = et.tolist()
+    if rank != 0:
+        return None, None, None
+    if sha_timed != sha_counted:
+        raise SystemExit("bench.py: the timed frame differs from the counted frame (%s vs %s) on %s" % (sha_timed, sha_counted, workload))
+
+    flags = scene.flags()
+    rays = total["rays_closest"] + total["rays_shadow"]
+    n_px = w * h
+    kname = kernel_name(flags, variant)
+    # roofline of the dominant kernel (the megakernel) on THIS rank: what it did / its duration
+    own_bytes = RF.alg_bytes(cnt, tr.count * 64)
+    entry = RF.find_entry(RF.load_inputs(), workload, spp, kname) if (world == 1 and variant == "megakernel") else None
+    if variant == "megakernel" and not flags["onchip"]:
+        rf = RF.l1_roofline(gnodes, cnt["tri_tests"], kernel_ms)
+        rf["global_node_fetches_per_launch"] = gnodes
+        rf["global_tri_tests_per_launch"] = cnt["tri_tests"]
+    else:
+        rf = RF.valu_roofline(entry, kernel_ms)
+        if rf is None:                                           # no PMC pass of this exact workload / kernel is committed
+            rf = {"bound": "valu", "achieved": None, "peak": RF.PEAK_VALU / 1e9, "unit": "Gwave-instr/s", "frac": None}
+        else:
+            rf["profile"] = {"file": "profiles/roofline_inputs.json", "workload": workload, "spp": spp, "source": entry.get("source")}
+    rf["traffic"] = RF.traffic_bytes(entry)
+    rf["kernel"] = kname
+    rf["kernel_ms"] = kernel_ms
+    rf["algorithmic"] = RF.algorithmic(own_bytes, kernel_ms)
+    out = {
+        "metric": "Mray/s", "value": rays * steps / elapsed / 1e6, "unit": "Mray/s",
+        "msample_per_s": n_px * spp * steps / elapsed / 1e6,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (workload if not spp_override else workload + " [spp overridden to %d]" % spp) +
+                               (" [opt-in box culling: not the reference's visiting set]" if culling else ""),
+                   "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "variant": variant, "seed": api.SEED,
+                   "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "kernel_flags": flags, "options": opts,
+                   "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
+                   "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
+        "frame_sha": sha_timed, "frame_equals_counted_frame": True,
+        "roofline": rf,
+    }
+    scene.close()
+    return out, sinfo, info
 
 
 def main():
@@ -98,6 +212,7 @@ def main():
     ap.add_argument("--workload", default="cornell_1920x1080_1024spp_depth8_mis", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (diagnostics only; the JSON then says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 secondary measurements (N = 1)")
     ap.add_argument("--variant", default="megakernel", choices=["megakernel", "wavefront"],
                     help="kernel organisation (SURVEY §8 f-1 A/B); the headline is the megakernel")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -128,87 +243,21 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
-    from cudapathtracer_amd import api, scenes
-    from cudapathtracer_amd import distributed as D
-
-    gen, kw = WORKLOADS[args.workload]
-    tmp = tempfile.mkdtemp(prefix="ptbench_r%d_" % rank)
-    sinfo = getattr(scenes, gen)(tmp, **kw)
-    host = api.HostScene(sinfo["config"])
-    info = host.info
-    w, h, md = info["width"], info["height"], info["max_depth"]
-    spp = args.spp or info["spp"]
-    cam = host.camera()
+    from cudapathtracer_amd import api
+    ctx = {"rank": rank, "world": world, "red_dev": red_dev, "share": share}
     opts = api.parse_options(args.opt)
-    scene = api.Scene(host, options=opts).set_variant(args.variant)           # scene resident in HBM from here on
-    if args.culling:
-        scene.set_culling(True)
+    out, sinfo, info = measure(ctx, args.workload, args.spp, args.steps, args.warmup, opts, args.variant, args.culling)
 
-    tr = api.rank_tiles(w, h, rank, world)
-    pad = D.padded_tile_count(w, h, world)
-    tiles = torch.zeros(pad, 64, 4, device="cuda")
-    frame = torch.zeros(h, w, 4, device="cuda") if rank == 0 else None
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(count_work=False):
-        tiles.zero_()                                           # out_colors starts at 0 (main.cu:339)
-        scene.render_tiles_device(cam, w, h, spp, md, tiles.data_ptr(), tiles=tr, count_work=count_work, stream=stream)
-        gathered = D.gather_tiles(tiles, w, h, rank, world)     # the path's single collective (N > 1)
-        if rank == 0:
-            D.assemble_device(gathered, w, h, world, frame, stream)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # counted pass (untimed): deterministic workload => these counts are exactly the timed steps' counts
-    scene.reset_counters()
-    step(count_work=True)
-    fence()
-    cnt = scene.counters()
-    cvec = torch.tensor([cnt[k] for k in api.COUNTER_KEYS], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(cvec)
-    total = dict(zip(api.COUNTER_KEYS, (int(v) for v in cvec.tolist())))
-
-    for _ in range(max(0, args.warmup - 1)):                    # the counted pass is the first warm-up
-        step()
-    fence()
-    kernel_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    # per-launch megakernel time from HIP events on its stream (last launch; all launches are identical)
-    kernel_ms = scene.last_kernel_ms()
-    et = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-    elapsed, kernel_ms_max = et.tolist()
-
+    plain = world == 1 and not args.spp and not args.opt and not args.culling and args.variant == "megakernel"
+    if rank == 0 and plain and not args.no_secondary and args.workload == "cornell_1920x1080_1024spp_depth8_mis":
+        # Driver-visible numbers for the kernel that serves scenes in HBM (BASELINE C3 at its full 1024 spp; the C4 / C5
+        # scene at 32 of its 4096 spp, depth 16): one counted + one timed step each, labelled.
+        sec = []
+        for wl, spp in (("blob82k_1920x1080_1024spp_depth8_mis", 0), ("atrium262k_1920x1080_4096spp_depth16_mis", 32)):
+            r, _, _ = measure(ctx, wl, spp, 1, 1, {}, "megakernel", False)
+            sec.append({k: r[k] for k in ("value", "unit", "msample_per_s", "steps", "ms_per_step", "config", "frame_sha", "frame_equals_counted_frame", "roofline")})
+        out["secondary"] = sec
     if rank == 0:
-        rays = total["rays_closest"] + total["rays_shadow"]
-        n_px = w * h
-        ms_per_step = elapsed / args.steps * 1e3
-        # roofline of the dominant kernel (the megakernel) on THIS rank: its algorithmic bytes / its duration
-        own_bytes = alg_bytes(cnt, tr.count * 64)
-        achieved = own_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        out = {
-            "metric": "Mray/s", "value": rays * args.steps / elapsed / 1e6, "unit": "Mray/s",
-            "msample_per_s": n_px * spp * args.steps / elapsed / 1e6,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (args.workload if not args.spp else args.workload + " [spp overridden to %d]" % spp) +
-                                   (" [opt-in box culling: not the reference's visiting set]" if args.culling else ""),
-                       "resolution": [w, h], "spp": spp, "max_depth": md, "integrator": "UNIDIRECTIONAL (MIS)", "variant": args.variant, "seed": api.SEED,
-                       "triangles": info["n_tris"], "bvh_nodes": info["n_nodes"], "kernel_flags": scene.flags(), "sharding": ("interleaved 8x8 tiles, 1 gather" + (" [REHEARSAL: all ranks share cuda:0, gloo]" if share else "")) if world > 1 else "none",
-                       "rays_per_step": rays, "box_tests_per_step": total["box_tests"], "tri_tests_per_step": total["tri_tests"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, spp) if (world == 1 and args.variant == "megakernel") else None,
-                         "kernel": (("pt::megakernel_hbm<0, false, %s, %s>" % (_tf(scene.flags()["culling"]), _tf(scene.flags()["refill"]))) if scene.flags()["hbm_kernel"] else "pt::megakernel<0, false, false, %s, %s, %s>" % (_tf(scene.flags()["onchip"]), _tf(scene.flags()["refill"]), _tf(scene.flags()["flat"]))) if args.variant == "megakernel" else "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": own_bytes},
-        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sinfo["config"], info)
         print(json.dumps(out), flush=True)

@@ -416,6 +416,12 @@ class Scene:
         _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
         return dict(zip(("regen", "closest", "bounce_logic", "wave_lifetimes", "not_earliest_start", "latest_end", "shadow_in_bounce", "slot7"), (int(v) for v in out)))
 
+    def global_node_fetches(self):
+        """Counting launches since reset_counters: internal-node fetches that missed the LDS scene cache (normal builds)."""
+        out = np.zeros(8, np.uint64)
+        _check(lib().pt_debug_stamps(self.h, _p(out)), "pt_debug_stamps")
+        return int(out[0])
+
     def debug_lane_util(self):
         """-DPT_UTIL builds, after a counting render: lanes carried per trip through the traversal loops."""
         out = np.zeros(8, np.uint64)

@@ -2,6 +2,7 @@
 // launcher boundary (launch_unidirectional / launch_naive_unidirectional, deviceCode.cuh:8-12)
 // and the probe entry points. Host code only; the kernels live in pt_kernels.hip.
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,7 @@ struct pt_scene {
     int numCU = 256;
     DeviceScene ds{};
     int stackNeed = 0, nInternal = 0, cacheNodes = 0, cacheTris = 0;
+    int nMats = 0, nLightsPacked = 0;
     bool armless = false;        // a triangle uses a material type without a dispatch arm (pt_path.h): DEFER is not exact
     // Everything below is set per scene through pt_set_option (names in quotes); the library reads no environment variable.
     int schedMask = 31;          // "sched_mask": scheduling checks every schedMask + 1 bounce iterations (tests use 3)
@@ -87,6 +89,13 @@ struct pt_scene {
 };
 
 static int queue_error(pt_scene* s);
+
+// LDS-resident instantiation: every PNode and PTri in the scene cache, the tree no deeper than the LDS stack, and the
+// records the bounce reads (PAttr, PMat, PLight) within their own LDS budget.
+static bool scene_onchip(const pt_scene* s) {
+    return s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0 &&
+           (kAttrCacheBytes == 0 || attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked) <= (size_t)kAttrCacheBytes);
+}
 
 extern "C" {
 
@@ -248,6 +257,11 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         L.a[0] = a.x; L.a[1] = a.y; L.a[2] = a.z; L.b[0] = b.x; L.b[1] = b.y; L.b[2] = b.z; L.c[0] = c.x; L.c[1] = c.y; L.c[2] = c.z;
         L.na[0] = d->normals[t.naInd].x; L.na[1] = d->normals[t.naInd].y; L.na[2] = d->normals[t.naInd].z;
         L.emission[0] = t.emission.x; L.emission[1] = t.emission.y; L.emission[2] = t.emission.z;
+        // area = 0.5f * length(cross3(b - a, c - a)) exactly as the kernels used to evaluate it per NEE sample: IEEE
+        // subtractions, cross = fma(p, q, -(r * s)), dot = fma(z, z', fma(y, y', x * x')), correctly rounded sqrt
+        const float ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z;
+        const float cx = fmaf(uy, vz, -(uz * vy)), cy = fmaf(uz, vx, -(ux * vz)), cz = fmaf(ux, vy, -(uy * vx));
+        L.area = 0.5f * sqrtf(fmaf(cz, cz, fmaf(cy, cy, cx * cx)));
     }
     // --- materials ---
     std::vector<PMat> mats(d->n_materials);
@@ -267,6 +281,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         p.eta[0] = m.eta.x; p.eta[1] = m.eta.y; p.eta[2] = m.eta.z;
         p.k[0] = m.k.x; p.k[1] = m.k.y; p.k[2] = m.k.z;
         p.absorption[0] = m.absorption.x; p.absorption[1] = m.absorption.y; p.absorption[2] = m.absorption.z;
+        p.albedoOverPi[0] = m.albedo.x / kPi; p.albedoOverPi[1] = m.albedo.y / kPi; p.albedoOverPi[2] = m.albedo.z / kPi;   // cosine_f, reflectors.cuh:10-13
     }
 
     if (!onDevice) {
@@ -299,6 +314,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
     s->ds.lights = (const PLight*)s->lights.p; s->ds.mats = (const PMat*)s->mats.p; s->ds.textures = (const float4*)s->textures.p;
     s->ds.rootRef = rootRef;
     s->ds.nLights = d->n_lights; s->ds.nTris = nT;
+    s->nMats = d->n_materials; s->nLightsPacked = std::max(d->n_lights, 1);
     s->ds.stackSpill = std::max(0, stackNeed - kStackLds);
     // scene cache: everything if it fits the LDS budget, else only the top of the (breadth-first) tree
     s->nTrisPacked = nT;
@@ -474,7 +490,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (int r = s->rng.ensure((size_t)t.count * 384 * sizeof(uint32_t))) return r;
     // Which kernel (pt_kernels.hip): the LDS-resident instantiation, or — for a scene in HBM — the 6-waves-per-SIMD
     // one with its shorter LDS stack (so the spill area is laid out for THAT stack length).
-    const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
+    const bool onchip = scene_onchip(s);
     const bool deferred = s->deferShadow && !s->armless;
     // ... and only with enough tiles to fill its 6 waves per SIMD: with fewer (a 1/8 shard of a 1080p frame is 4050
     // tiles for 6144 slots) the extra slots stay empty and the 4-wave kernel's faster waves win (measured: 1/8 shard
@@ -495,6 +511,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
+    P.cacheAttrs = P.cacheMats = P.cacheLights = 0;
+    if (onchip && kAttrCacheBytes > 0) { P.cacheAttrs = s->nTrisPacked; P.cacheMats = s->nMats; P.cacheLights = s->nLightsPacked; }   // the bounce's records in LDS as well
     P.wgWaves = wgWaves;
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, kCacheBytesHbm / 64);     // its workgroups share a larger copy of the top of the tree
     P.xcdBands = s->xcdBands ? 1 : 0;
@@ -748,7 +766,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
 
 int pt_scene_flags(pt_scene* s) {
     if (!s) return 0;
-    const bool onchip = s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0;
+    const bool onchip = scene_onchip(s);
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);

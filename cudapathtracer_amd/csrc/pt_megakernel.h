@@ -1,0 +1,416 @@
+// pt_megakernel.h — the megakernel (Li_unidirectional / Li_naive_unidirectional with the reference's host sample loop
+// inside, deviceCode.cu:158-205, 285-542, 568-573), its tile queue and its two entry points. Included by the two
+// translation units that instantiate it: pt_mk_lds.hip (scenes that live in LDS; VALU-bound, built with
+// -fno-slp-vectorize: packed f32 instructions do not issue at twice the scalar rate and cost pair moves, -2.3 % on
+// Cornell) and pt_mk_hbm.hip (scenes in HBM; latency-bound, +1 % WITH the vectorizer).
+//
+// Execution shape: one wave64 owns one 8x8-pixel tile (lane = ly*8+lx); a workgroup is 4 (or 12) independent waves that
+// share one LDS scene cache. Every lane walks its pixel's samples in order (the per-pixel stream is sequential by
+// construction) and lanes REGENERATE: a lane whose path ended starts its pixel's next sample at the top of the next
+// bounce iteration, so the wave keeps 64 live rays for traversal until the pixels run out of samples.
+#pragma once
+#include "pt_path.h"
+#include "pt_params.h"
+
+namespace pt {
+
+PT_DEV void wave_add_total(unsigned long long* totals, int k, uint32_t v) {
+    unsigned long long s = v;
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&totals[k], s);
+}
+
+// Dynamic LDS of one workgroup: [scene cache: nodes | tris][4 traversal stacks][4 medium stacks].
+extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
+
+// All threads of the workgroup copy the cached part of the scene into LDS (16 B per thread per step). attrOff > 0
+// (LDS-resident scenes): the records the bounce reads — nA PAttr, nM PMat, nL PLight — go to byte offset attrOff too.
+PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int cacheTris, int attrOff = 0, int nA = 0, int nM = 0, int nL = 0) {
+    typedef __attribute__((address_space(3))) f4v lds_f4;
+    lds_f4* dstN = (lds_f4*)pt_smem;
+    lds_f4* dstT = dstN + cacheNodes * 4;
+    const f4v* srcN = reinterpret_cast<const f4v*>(S.nodes);
+    const f4v* srcT = reinterpret_cast<const f4v*>(S.tris);
+    for (int i = threadIdx.x; i < cacheNodes * 4; i += blockDim.x) dstN[i] = srcN[i];
+    for (int i = threadIdx.x; i < cacheTris * 3; i += blockDim.x) dstT[i] = srcT[i];
+    if (attrOff > 0) {
+        lds_f4* dA = (lds_f4*)(pt_smem + attrOff);
+        lds_f4* dM = dA + nA * 5;
+        lds_f4* dL = dM + nM * 6;
+        const f4v* sA = reinterpret_cast<const f4v*>(S.attrs);
+        const f4v* sM = reinterpret_cast<const f4v*>(S.mats);
+        const f4v* sL = reinterpret_cast<const f4v*>(S.lights);
+        for (int i = threadIdx.x; i < nA * 5; i += blockDim.x) dA[i] = sA[i];
+        for (int i = threadIdx.x; i < nM * 6; i += blockDim.x) dM[i] = sM[i];
+        for (int i = threadIdx.x; i < nL * 4; i += blockDim.x) dL[i] = sL[i];
+    }
+    __syncthreads();
+    SceneCache C;
+    C.nodes = (lds_cf4*)dstN; C.nNodes = cacheNodes;
+    C.tris = (lds_cf4*)dstT; C.nTris = cacheTris;
+    return C;
+}
+
+// Diagnostic build only (-DPT_STAMPS): wave-level s_memtime shares, summed into totals[8..9]
+// (logic step, traversal). Never quote this build's run time (cdna_hip_programming.md §7).
+#ifdef PT_STAMPS
+#define PT_STAMP(slot) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp[slot] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define PT_STAMP(slot) do {} while (0)
+#endif
+
+PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
+    if (defer && (ps.flags & kShadowPending)) { ps.LiFinish = ps.Li; ps.flags |= kFinishPending; }   // last NEE term still in flight
+    else acc = acc + ps.Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
+    ps.flags &= ~kInPath;
+}
+
+// ---- tile queue of the persistent megakernel -------------------------------------------------
+// A bounded multi-producer / multi-consumer ring in global memory:
+//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] error, q[4] sum of remaining samples
+//   of the tiles being worked on, q[5] waves working; from q + 8: cap 64-bit slots {sequence, item}
+//   (cap = mask + 1 >= tiles; Vyukov's scheme: slot p%cap holds sequence p+1 when push p is in it, and
+//   p+cap once pop p has taken it). It starts holding every tile once (kFreshBit). A wave that yields a
+//   tile at the end of a time slice pushes it back; a tile is in the ring at most once, so it cannot overflow.
+// Memory model. A yielded tile's state (RNG, accumulator, samples left) moves between waves on different
+// XCDs, whose L2s are not coherent with each other. Fences at agent scope would do it, but on gfx950 they
+// write back / invalidate the whole L2 each time — measured 3x slower on the 263 k-triangle scene. Instead
+// every access to queue words and tile state inside the kernel is a relaxed agent-scope atomic (sc1: served
+// at the memory side, never from a possibly stale cache line), slot and item travel in ONE 64-bit word, and
+// "state before the queue entry" is the wave waiting for its own stores: an explicit `s_waitcnt vmcnt(0)` between the
+// last state store and queue_push (see the end of megakernel_body; no fence emits it by itself).
+// Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
+// surface as an error code, never as a hung GPU.
+constexpr int kFreshBit = 1 << 30;
+constexpr unsigned long long kQueueTimeout = 3000000000ull;            // 30 s of the 100 MHz wall clock without any progress
+#define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
+PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
+    int item = -1;
+    if (lane == 0) {
+        const unsigned pos = atomicAdd((unsigned*)&q[0], 1u);
+        unsigned long long* slot = queue_slot(q, mask, pos);
+        unsigned long long t0 = wall_clock64();
+        int seen = -1;
+        for (unsigned spin = 0;; spin++) {
+            const unsigned long long v = PT_QLOAD(slot);
+            if ((unsigned)v == pos + 1u) {
+                item = (int)(v >> 32);
+                PT_QSTORE(slot, (unsigned long long)(pos + (unsigned)mask + 1u));
+                break;
+            }
+            if (!mayWait) break;                                                // without time slices nothing is ever pushed
+            if ((spin & 7) == 0) {
+                const int done = PT_QLOAD(&q[2]);
+                if (done >= nTiles || PT_QLOAD(&q[3]) != 0) break;              // frame finished, or somebody gave up
+                // the clock only runs while nothing moves: every running wave pushes or finishes within one time
+                // slice, so the end of a long frame (fewer tiles left than waves) is not a timeout
+                const int progress = done + PT_QLOAD(&q[1]);
+                const unsigned long long now = wall_clock64();
+                if (progress != seen) { seen = progress; t0 = now; }
+                else if (now - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 1); break; }
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(item);
+}
+PT_DEV void queue_push(int* q, int mask, int item, int lane) {
+    if (lane == 0) {
+        const unsigned pos = atomicAdd((unsigned*)&q[1], 1u);
+        unsigned long long* slot = queue_slot(q, mask, pos);
+        const unsigned long long t0 = wall_clock64();
+        while ((unsigned)PT_QLOAD(slot) != pos) {
+            if (PT_QLOAD(&q[3]) != 0) return;
+            if (wall_clock64() - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 2); return; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        PT_QSTORE(slot, ((unsigned long long)(unsigned)item << 32) | (unsigned long long)(pos + 1u));
+    }
+}
+// Tile state words: plain accesses when one wave owns the tile for the whole kernel, memory-side ones when
+// tiles can change hands (see above).
+PT_DEV uint32_t state_load(const uint32_t* p, bool shared) { return shared ? PT_QLOAD(p) : *p; }
+PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_QSTORE(p, v); else *p = v; }
+
+// INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
+// scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
+// stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false>
+PT_DEV void megakernel_body(const KParams& P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
+    DeviceScene S = P.S;
+    // ONCHIP kernels: the host guarantees that the bounce's records fit as well (pt_api.hip: `onchip`), so their address
+    // space is a compile-time fact and every access below is a ds_read.
+    constexpr bool ATTRLDS = ONCHIP && kAttrCacheBytes > 0;
+    const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMediumMax * 64) : 0;
+    const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights);      // contains the only barrier
+    if constexpr (ATTRLDS) {
+        // The bounce reads its records through S; pointing S at the LDS copies makes those loads ds_reads (the address
+        // space is visible to the compiler: everything below is inlined into this function).
+        typedef __attribute__((address_space(3))) const PAttr lds_attr;
+        typedef __attribute__((address_space(3))) const PMat lds_mat;
+        typedef __attribute__((address_space(3))) const PLight lds_light;
+        lds_attr* a = (lds_attr*)(pt_smem + attrOff);
+        lds_mat* m = (lds_mat*)(pt_smem + attrOff + P.cacheAttrs * 80);
+        lds_light* l = (lds_light*)(pt_smem + attrOff + P.cacheAttrs * 80 + P.cacheMats * 96);
+        S.attrs = (const PAttr*)a; S.mats = (const PMat*)m; S.lights = (const PLight*)l;
+    }
+    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2. Default: tile =
+    // blockIdx order, i.e. the XCDs interleave over the frame at 32x8-pixel granularity — every XCD gets
+    // the same mix of cheap and expensive regions. xcdBands (PT_XCD_BANDS=1) instead gives each XCD one
+    // contiguous band so its L2 holds only that band's geometry; measured: no gain on the 263 k scene
+    // (secondary rays leave the band at once), -14 % / -9 % on the 82 k scene / Cornell (bands differ
+    // in cost and a static 1/8 split cannot rebalance). Kept as the A/B switch.
+    int vb = blockIdx.x;
+    if (P.xcdBands) {
+        const int nB = gridDim.x, q = nB >> 3, r = nB & 7, x = vb & 7;
+        vb = x * q + (x < r ? x : r) + (vb >> 3);
+    }
+    // Persistent waves (P.queue != null): the grid only fills the chip and every wave takes its next tile
+    // from the queue, so a wave slot is never parked behind the slowest of four sibling waves or behind
+    // workgroup launch; tiles are independent, so the order does not reach the image.
+    for (bool first = true;; first = false) {
+    int lt;
+    bool fresh = true;
+    if (P.queue) {
+        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0);
+        if (item < 0) break;
+        fresh = (item & kFreshBit) != 0;
+        lt = item & ~kFreshBit;
+    } else {
+        if (!first) break;
+        lt = vb * nW + wave;
+    }
+    if (lt >= P.tileCount) break;
+    const int tile = P.tileFirst + lt * P.tileStride;
+    const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
+    const bool inImage = (x < P.w) && (y < P.h);
+
+    const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
+    Stack<STACKN> st;
+    st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (STACKN * 64) + lane;
+    st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * nW + wave) * S.stackSpill) * 64 + lane : nullptr;
+    st.sp = 0;
+    LdsMedium ms;
+    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + nW * STACKN * 256) + wave * (kMediumMax * 64) + lane;
+
+    PathState ps;
+    const bool shared = P.queue != nullptr && !COUNT && P.sliceIters > 0;       // tiles may change hands
+    {
+        const uint32_t* r = P.rng + (size_t)lt * 384 + lane;
+        ps.rng.v0 = state_load(r, shared); ps.rng.v1 = state_load(r + 64, shared); ps.rng.v2 = state_load(r + 128, shared);
+        ps.rng.v3 = state_load(r + 192, shared); ps.rng.v4 = state_load(r + 256, shared); ps.rng.d = state_load(r + 320, shared);
+    }
+    ps.o = v3(0.0f); ps.d = v3(0.0f); ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
+    ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps; ps.depth = 0; ps.guard = 0; ps.msTop = 1; ps.flags = 0;
+    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; ps.LiFinish = v3(0.0f);
+    float4 acc4;
+    {
+        const uint32_t* o = (const uint32_t*)(P.out + (size_t)lt * 64 + lane);
+        acc4 = make_float4(__uint_as_float(state_load(o, shared)), __uint_as_float(state_load(o + 1, shared)),
+                           __uint_as_float(state_load(o + 2, shared)), __uint_as_float(state_load(o + 3, shared)));
+    }
+    V3 acc = v3(acc4.x, acc4.y, acc4.z);
+    Ctr c = {};
+    int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
+    Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+    V3 thr = v3(1.0f);
+    RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
+    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
+#ifdef PT_STAMPS
+    unsigned long long stamp[4] = {0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long wall0 = wall_clock64();     // device-wide 100 MHz clock: slot occupancy (tools/stamps.py)
+#endif
+    auto shadowSync = [&](V3 ro, V3 wi, float maxt) {
+        PT_STAMP(2);
+        V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+#ifdef PT_DIAG_DOUBLE_SHADOW        // cost measurement only (tools/phase_cost.sh): the shadow ray traced twice, same result
+        {
+            const V3 t2_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+            t_ = v3(fminf_(t_.x, t2_.x), fminf_(t_.y, t2_.y), fminf_(t_.z, t2_.z));
+        }
+#endif
+        PT_STAMP(3);
+        return t_;
+    };
+
+    // Every iteration: one logic step per lane (finish the previous bounce's NEE, shade the hit,
+    // regenerate if the path ended), then one traversal round for the rays the logic produced. A
+    // lane whose path ended starts its pixel's next sample in the same step, so the wave keeps 64
+    // live rays until the pixels run out of samples; a ballot ends the wave.
+    // Longest-remaining-first inside a SIMD (P.lptPrio). Once the tile cursor is exhausted no slot gets
+    // new work and the kernel ends with its slowest pixel chain (a pixel's samples are one sequential RNG
+    // stream, so a chain cannot be split); a wave that is alone on its SIMD runs latency-bound, far below
+    // the SIMD's throughput. Waves publish their remaining samples; a wave with more left than the mean
+    // of the waves still running raises its issue priority (s_setprio), so the long chains advance at
+    // near single-wave speed while the short ones fill the gaps — the image does not depend on it.
+    // Time slices (P.sliceIters). With no fresh tile left, what each SIMD still has to do is whatever its
+    // four waves happen to hold, and the sums differ (measured: the worst SIMD carries ~1.3x the mean when
+    // every slot holds exactly one tile, the 8-GPU case). So from then on a wave works on a tile for
+    // sliceIters bounce iterations, lets its lanes finish the paths in flight (no new samples), writes the
+    // tile's state back (RNG, accumulator, samples left per pixel) and queues it again; the next free wave —
+    // on any SIMD — continues it. The per-pixel streams continue exactly where they stopped.
+    int itc = 0, myRem = 0, sliceEnd = 0x7fffffff;
+    bool stopStarting = false;
+    const bool lpt = P.queue != nullptr && P.lptPrio != 0;
+    if (lpt) {
+        myRem = samplesLeft;
+        for (int o = 32; o; o >>= 1) myRem = max(myRem, __shfl_xor(myRem, o));
+        if (lane == 0) { atomicAdd(&P.queue[5], 1); atomicAdd(&P.queue[4], myRem); }
+    }
+    while (true) {
+        if (P.queue && ((++itc) & P.schedMask) == 0) {
+            const bool exhausted = PT_QLOAD(&P.queue[0]) >= P.tileCount;
+            if (!COUNT && P.sliceIters > 0 && (exhausted || P.sliceAlways)) {
+                if (sliceEnd == 0x7fffffff) sliceEnd = itc + P.sliceIters;
+                else if (itc >= sliceEnd) stopStarting = true;
+            }
+            if (lpt) {
+                int rem = samplesLeft + ((ps.flags & kInPath) ? 1 : 0);
+                for (int o = 32; o; o >>= 1) rem = max(rem, __shfl_xor(rem, o));
+                if (lane == 0 && rem != myRem) atomicAdd(&P.queue[4], rem - myRem);
+                myRem = rem;
+                int prio = 0;
+                if (exhausted || P.lptPrio == 2) {
+                    const long long sum = PT_QLOAD(&P.queue[4]), a = PT_QLOAD(&P.queue[5]), act = a > 0 ? a : 1;
+                    const long long r10 = 10ll * rem * act;
+                    prio = r10 >= 13 * sum ? 3 : (r10 >= 11 * sum ? 2 : (r10 >= 9 * sum ? 1 : 0));
+                }
+                if (prio == 3) __builtin_amdgcn_s_setprio(3);
+                else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+                else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if (REFILL) {
+            // Lanes whose rays are done take their logic step (DEFER form: the shadow ray is recorded, not traced
+            // inside the bounce) and start their next pair of rays; lanes still tracing skip it and resume below.
+            if (!(rs.flags & kRayBusy)) {
+                apply_pending(ps, thr, acc);
+                if (ps.flags & kInPath) {
+                    bool done = path_bounce<INTEG, COUNT, true>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+                    if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
+                    if (done) path_finish(ps, acc, true);
+                }
+                while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
+                    samplesLeft--;
+                    path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+                    if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, true);
+                }
+                const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
+                if (hasExt || hasShadow) ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+            }
+            PT_STAMP(2);
+            const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
+            if (nBusy == 0) break;
+            trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            PT_STAMP(1);
+            continue;
+        }
+        if (DEFER) apply_pending(ps, thr, acc);
+        if (ps.flags & kInPath) {
+            bool done = path_bounce<INTEG, COUNT, DEFER>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+            if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
+            if (done) path_finish(ps, acc, DEFER);
+        }
+        PT_STAMP(2);                                   // slot 2: scheduling check + bounce logic (shading, NEE shadow ray)
+        while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
+            samplesLeft--;
+            path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+            if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, DEFER);
+        }
+        const bool hasExt = (ps.flags & kInPath) != 0;
+        const bool hasShadow = DEFER && (ps.flags & kShadowPending) != 0;
+        PT_STAMP(0);
+        if (__ballot(hasExt || hasShadow) == 0ull) break;
+        if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+        else if constexpr (FLAT) {
+            trace_closest_flat<STACKN>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes);
+#ifdef PT_DIAG_DOUBLE_CLOSEST       // cost measurement only: the closest-hit traversal run twice, same result
+            { Hit h2; trace_closest_flat<STACKN>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h2, c, P.cacheNodes); if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); }
+#endif
+        }
+        else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, Keep{P.nodeKeep, P.triKeep});
+        PT_STAMP(1);
+    }
+
+    if (lpt) {
+        if (lane == 0) { atomicAdd(&P.queue[4], -myRem); atomicAdd(&P.queue[5], -1); }
+        __builtin_amdgcn_s_setprio(0);
+    }
+#ifdef PT_STAMPS
+    if (P.totals && lane == 0) {
+        for (int k = 0; k < 3; k++) atomicAdd(&P.totals[8 + k], stamp[k]);   // regeneration, closest-hit traversal, bounce logic
+        atomicAdd(&P.totals[14], stamp[3]);                                    // shadow rays traced inside the bounce (SYNC kernels)
+        const unsigned long long wall1 = wall_clock64();
+        atomicAdd(&P.totals[11], wall1 - wall0);             // sum of wave lifetimes
+        atomicMax(&P.totals[12], ~wall0);                     // ~(earliest start)
+        atomicMax(&P.totals[13], wall1);                      // latest end
+    }
+#endif
+    if (inImage) {
+        uint32_t* o = (uint32_t*)(P.out + (size_t)lt * 64 + lane);
+        state_store(o, __float_as_uint(acc.x), shared); state_store(o + 1, __float_as_uint(acc.y), shared);
+        state_store(o + 2, __float_as_uint(acc.z), shared); state_store(o + 3, __float_as_uint(acc4.w), shared);
+    }
+    {
+        uint32_t* r = P.rng + (size_t)lt * 384 + lane;
+        state_store(r, ps.rng.v0, shared); state_store(r + 64, ps.rng.v1, shared); state_store(r + 128, ps.rng.v2, shared);
+        state_store(r + 192, ps.rng.v3, shared); state_store(r + 256, ps.rng.v4, shared); state_store(r + 320, ps.rng.d, shared);
+    }
+    if (P.queue) {
+        int left = samplesLeft;
+        for (int o = 32; o; o >>= 1) left = max(left, __shfl_xor(left, o));
+        if (left > 0) {                                // yielded: somebody else continues this tile
+            state_store((uint32_t*)P.left + (size_t)lt * 64 + lane, (uint32_t)samplesLeft, true);
+            // "State before the queue entry": the wave waits for its OWN stores — every state word above is an sc1 store
+            // counted in vmcnt (gfx9 counts stores there, in issue order), so vmcnt(0) means the memory side has them all.
+            // An explicit s_waitcnt, not a fence: a workgroup-scope release fence compiles to nothing here (the two sc1
+            // stores came out back to back), an agent-scope one writes back the whole L2 (3x slower). The
+            // "memory" clobber keeps the compiler from moving the queue accesses above it; tests/test_isa.py checks the
+            // instruction order in every non-counting instantiation.
+            asm volatile("; PT_YIELD_STATE_STORED\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            queue_push(P.queue, P.queueMask, lt, lane);
+        } else if (lane == 0) atomicAdd(&P.queue[2], 1);
+    }
+    if (COUNT) {
+        if (P.pixCounters) {
+            uint32_t* pc = P.pixCounters + (size_t)lt * 512 + lane;
+            pc[0] = c.raysClosest; pc[64] = c.raysShadow; pc[128] = c.pops; pc[192] = c.boxes;
+            pc[256] = c.tris; pc[320] = c.hits; pc[384] = c.draws; pc[448] = c.iters;
+        }
+        if (P.totals) {
+            wave_add_total(P.totals, 0, c.raysClosest); wave_add_total(P.totals, 1, c.raysShadow);
+            wave_add_total(P.totals, 2, c.pops); wave_add_total(P.totals, 3, c.boxes);
+            wave_add_total(P.totals, 4, c.tris); wave_add_total(P.totals, 5, c.hits);
+            wave_add_total(P.totals, 6, c.draws); wave_add_total(P.totals, 7, c.iters);
+#ifdef PT_UTIL
+            for (int k = 0; k < 8; k++) wave_add_total(P.totals, 8 + k, c.u[k]);     // in the slots of the PT_STAMPS diagnostic
+#elif !defined(PT_STAMPS)
+            wave_add_total(P.totals, 8, c.gnodes);                                    // pt_debug_stamps()[0] in a normal build
+#endif
+        }
+    }
+    }   // next tile
+}
+
+// Two register budgets (PMC counters): a scene that lives in LDS is VALU-bound and best at
+// 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
+// cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
+// included (5: +10 %, 7-8: no better). Both run the same body.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false>
+__global__ void __launch_bounds__(256)
+#if PT_MIN_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
+#endif
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT>(P); }
+
+template <int INTEG, bool COUNT, bool CULL, bool REFILL>
+__global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL>(P); }
+
+
+}  // namespace pt

@@ -1,0 +1,31 @@
+// pt_mk_hbm.hip — megakernel instantiations for scenes in HBM: megakernel_hbm (6 waves per SIMD, 12-wave workgroups
+// sharing a 44 KB copy of the top of the tree; loop exits, REFILL, opt-in culling) and the general 4-wave kernel
+// (launches with too few tiles to fill six waves per SIMD; the DEFER A/B instantiation). Latency-bound; built with the
+// default flags (the SLP vectorizer is worth +1 % here).
+#include "pt_megakernel.h"
+
+namespace pt {
+
+hipError_t launch_megakernel_hbm(int integrator, bool count, bool syncShadow, bool hbm, const KParams& P, dim3 grid, dim3 block, unsigned lds, hipStream_t stream) {
+    // more than 64 KB of dynamic LDS per workgroup has to be asked for (a workgroup may take all 160 KB of its CU)
+#define PT_LDS_OK(K) do { if (lds > 65536u) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e_ != hipSuccess) return e_; } } while (0)
+#define PT_LAUNCH_MK(I, C, D, RF) hipLaunchKernelGGL((megakernel<I, C, D, false, RF>), grid, block, lds, stream, P)
+#define PT_LAUNCH_HBM1(I, C, CU, RF) do { PT_LDS_OK((megakernel_hbm<I, C, CU, RF>)); hipLaunchKernelGGL((megakernel_hbm<I, C, CU, RF>), grid, block, lds, stream, P); } while (0)
+#define PT_LAUNCH_HBM(I, C) do { if (P.cull) PT_LAUNCH_HBM1(I, C, true, false); else if (P.refill) PT_LAUNCH_HBM1(I, C, false, true); \
+                                 else PT_LAUNCH_HBM1(I, C, false, false); } while (0)
+#define PT_PICK(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
+                        else if (P.refill) { if (count) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, false, false, true); } \
+                        else if (count) PT_LAUNCH_MK(I, true, false, false); \
+                        else PT_LAUNCH_MK(I, false, false, false); } while (0)
+    if (integrator == 2) PT_PICK(2);
+    else if (syncShadow) PT_PICK(0);
+    else { if (count) PT_LAUNCH_MK(0, true, true, false); else PT_LAUNCH_MK(0, false, true, false); }
+#undef PT_PICK
+#undef PT_LAUNCH_HBM
+#undef PT_LAUNCH_HBM1
+#undef PT_LAUNCH_MK
+#undef PT_LDS_OK
+    return hipGetLastError();
+}
+
+}  // namespace pt

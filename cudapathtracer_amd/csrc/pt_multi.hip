@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -73,6 +74,10 @@ struct Rank {
 }  // namespace
 
 struct pt_multi {
+    // Ranks that share a device (rehearsals on a box with fewer GPUs than ranks) render one after another: the megakernel
+    // is persistent — its grid fills the chip and its waves wait on a tile queue — so two of them on one device only
+    // oversubscribe it. Ranks on different devices run concurrently.
+    std::mutex deviceLock[PT_MULTI_MAX_DEVICES];
     int n = 0;
     std::vector<Rank> ranks;
     void* dGather = nullptr; size_t gatherBytes = 0;    // on device ranks[0].device: [rank][padded tiles][64] float4
@@ -254,6 +259,9 @@ int pt_multi_render(pt_multi* m, const pt_camera* cam, int w, int h, int spp, in
         pt_rank_tiles(w, h, r, N, &tr);
         if (ensure(k.dColors, k.colorsBytes, frameBytes) || ensure(k.dTiles, k.tilesBytes, slotBytes)) { k.err = "hipMalloc failed"; return -2; }
         if (r == 0 && ensure(m->dGather, m->gatherBytes, slotBytes * (size_t)N)) { k.err = "hipMalloc failed"; return -2; }
+        int firstOnDevice = r;                                             // the lowest rank on this device names its lock
+        for (int q = 0; q < r; q++) if (m->ranks[q].device == k.device) { firstOnDevice = q; break; }
+        std::lock_guard<std::mutex> oneKernelPerDevice(m->deviceLock[firstOnDevice]);
         if (hipMemcpyAsync(k.dColors, out_rgba_sum, frameBytes, hipMemcpyHostToDevice, k.stream) != hipSuccess) { k.err = "H2D copy failed"; return -2; }
         if (hipMemsetAsync(k.dTiles, 0, slotBytes, k.stream) != hipSuccess) { k.err = "memset failed"; return -2; }
         if (int rc = pt_tile_device(w, h, &tr, k.dColors, k.dTiles, k.stream)) return rc;        // colors[pixelIdx] += Li: the sum starts from `out`

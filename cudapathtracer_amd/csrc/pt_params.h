@@ -26,6 +26,13 @@ constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
 constexpr int kStackLdsHbm = PT_STACK_LDS_HBM;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
 constexpr int kCacheBytes = PT_CACHE_BYTES;
+// LDS-resident scenes also stage what the bounce reads — hit attributes (80 B per triangle), materials (96 B each) and lights
+// (64 B each) — when those fit this budget, so that the logic step has no global load (Cornell: 36 x 80 + 24 x 96 + 2 x 64 =
+// 5.3 KB; a bounce otherwise waits on five dependent L2 round trips at 4 waves per SIMD). 0 = never (A/B).
+#ifndef PT_ATTR_CACHE_BYTES
+#define PT_ATTR_CACHE_BYTES 8192
+#endif
+constexpr int kAttrCacheBytes = PT_ATTR_CACHE_BYTES;
 // The kernel for scenes in HBM runs in workgroups of PT_WG_WAVES_HBM waves (default 12: two workgroups per CU at 6
 // waves per SIMD) so that its waves SHARE one large LDS copy of the top of the tree instead of six small ones:
 // 80 KB per workgroup - 12 x (2 KB stack + 1 KB medium stack) = 44 KB = the first 704 PNodes, which take 45 % of all
@@ -43,6 +50,7 @@ struct KParams {
     int w, h, spp, maxDepth, useMIS;
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
+    int cacheAttrs, cacheMats, cacheLights;   // ONCHIP kernels: PAttr / PMat / PLight records staged behind the stacks (all or none; 0 = read from global memory)
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
     int triKeep;                   // ... and its triangle loop once no more than entered * triKeep / 16 lanes still have triangles in their leaf
     int nodeKeep;                  // a wave leaves its node loop once no more than active * nodeKeep / 16 lanes are still descending (pt_trace.h); 0 = when none is
@@ -132,8 +140,9 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
 // waves a probe_closest/shadow launch of n rays uses (spill sizing)
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
 inline int megakernel_blocks(int tileCount, int wgWaves = 4) { return (tileCount + wgWaves - 1) / wgWaves; }
-inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4) {
-    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (size_t)kMediumMax * 64);
+inline size_t attr_cache_bytes(int nAttrs, int nMats, int nLights) { return (size_t)nAttrs * 80 + (size_t)nMats * 96 + (size_t)nLights * 64; }
+inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4, size_t attrBytes = 0) {
+    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (size_t)kMediumMax * 64) + attrBytes;
 }
 
 }  // namespace pt

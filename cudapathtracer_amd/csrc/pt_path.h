@@ -153,21 +153,23 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
     const PMat& m = S.mats[hi.material];
     if (INTEG == 2) {
         // ---- Li_naive_unidirectional, deviceCode.cu:183-201 ----
-        V3 toSurface = to_local(d, hi.normal);
+        const Onb frame = onb_of(hi.normal);
+        V3 toSurface = to_local(d, frame);
         V3 f = v3(0.0f), toNext = v3(0.0f);
         float p = 0.0f;
         sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
         if (p <= 0.0f || dot(f, f) < kEps) return true;
         Li = Li + hi.emission * beta;
         beta = beta * ((f * __builtin_fabsf(toNext.z)) / p);
-        V3 nw = to_world(toNext, hi.normal);
+        V3 nw = to_world(toNext, frame);
         o = hi.point + ((toNext.z > 0.0f) ? (hi.normal * kRayEps) : ((-hi.normal) * kRayEps));
         d = nw;
         depth++;
         return false;
     }
     // ---- Li_unidirectional, deviceCode.cu:332-537 ----
-    V3 wiLocal = to_local(d, hi.normal);
+    const Onb frame = onb_of(hi.normal);                 // toLocal / toWorld of this bounce all use the hit's normal
+    V3 wiLocal = to_local(d, frame);
     const bool isSpecular = (m.flags & kMatSpecular) != 0;
     bool trueHit = true;
     int minPriorID = ms.get(0);
@@ -178,7 +180,9 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         if (pr < minPrior) { minPrior = pr; minPriorID = id; }
     }
     const PMat& dom = S.mats[minPriorID];
-    if (hi.dist > kEps) {
+    // Beer-Lambert, deviceCode.cu:362-368. A medium that does not absorb (air, plain glass: absorption exactly 0) gives
+    // exp(-+0) = 1.0f exactly in this arithmetic and beta * 1.0f = beta bit for bit, so the three exps are skipped.
+    if (hi.dist > kEps && !(dom.absorption[0] == 0.0f && dom.absorption[1] == 0.0f && dom.absorption[2] == 0.0f)) {
         V3 att = v3(exp_(-dom.absorption[0] * hi.dist), exp_(-dom.absorption[1] * hi.dist), exp_(-dom.absorption[2] * hi.dist));
         beta = beta * att;
     }
@@ -219,8 +223,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
                     V3 wi = normalize(s2l);
                     float dist2 = dot(s2l, s2l);
                     float cosL = dot(ld3(L.na), -wi);
-                    float area = 0.5f * length(cross(ld3(L.b) - ld3(L.a), ld3(L.c) - ld3(L.a)));
-                    lightPdf = dist2 / (cosL * (float)S.nLights * area);
+                    lightPdf = dist2 / (cosL * (float)S.nLights * L.area);
                 }
                 if (lightPdf > kEps) {
                     float wB = pdf * pdf / (lightPdf * lightPdf + pdf * pdf);
@@ -254,9 +257,8 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
                 float dist2 = dot(s2l, s2l);
                 float cosL = dot(ld3(L.na), -wi);
                 float cosS = __builtin_fabsf(dot(hi.normal, wi));
-                float area = 0.5f * length(cross(B - A, Cc - A));
-                float lightPdf = dist2 / (cosL * (float)S.nLights * area);
-                V3 wiL = to_local(wi, hi.normal);
+                float lightPdf = dist2 / (cosL * (float)S.nLights * L.area);
+                V3 wiL = to_local(wi, frame);
                 if (!DEFER) woLocal = wiL;
                 V3 f = f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
                 V3 nee = ((f * ld3(L.emission)) * cosS) / lightPdf;
@@ -278,7 +280,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         }
         V3 f = v3(0.0f);
         sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
-        V3 woWorld = to_world(woLocal, hi.normal);
+        V3 woWorld = to_world(woLocal, frame);
         pdf = fmaxf_(pdf, 0.01f);
         if (woLocal.z < 0.0f) {
             if (!hi.backface) { if (msTop < 16) { ms.set(msTop, hi.material); msTop++; } }
@@ -290,7 +292,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         d = normalize(woWorld);
         prevPoint = hi.point;
     } else {
-        woLocal = to_local(d, hi.normal);
+        woLocal = wiLocal;                               // toLocal(ray.direction, normal) again (deviceCode.cu:516): the value computed above
         o = hi.point + d * kRayEps;
         depth--;
     }

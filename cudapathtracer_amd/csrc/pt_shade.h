@@ -48,13 +48,20 @@ PT_DEV V3 to_local(V3 w, V3 n) {
     V3 b = cross(n, t);
     return v3(dot(w, t), dot(w, b), dot(w, n));
 }
+// The reference rebuilds the basis in every toLocal / toWorld call (util.cuh:163-185), three times per bounce on the
+// same normal; it is a pure function of n, so one bounce builds it once (same values).
+struct Onb { V3 t, b, n; };
+PT_DEV Onb onb_of(V3 n) { Onb f; f.t = onb_tangent(n); f.b = cross(n, f.t); f.n = n; return f; }
+PT_DEV V3 to_world(V3 l, const Onb& f) { return l.x * f.t + l.y * f.b + l.z * f.n; }
+PT_DEV V3 to_local(V3 w, const Onb& f) { return v3(dot(w, f.t), dot(w, f.b), dot(w, f.n)); }
 
 // ---- reflectors.cuh ---------------------------------------------------------------------
 PT_DEV V3 cosine_f(V3 base) { return base / kPi; }                                           // :10-13
 PT_DEV float cosine_pdf(V3 wo) { return fmaxf_(wo.z, kEps) / kPi; }                           // :15-18
 
+// fPre: cosine_f(base) where the caller already has it (untextured materials: albedo / PI from scene set-up), else null.
 template <bool COUNT>
-PT_DEV void cosine_sample_f(Rng& rng, V3 base, V3& wo, V3& f, float& pdf, Ctr& c) {          // :21-39
+PT_DEV void cosine_sample_f(Rng& rng, V3 base, V3& wo, V3& f, float& pdf, Ctr& c, const float* fPre = nullptr) {          // :21-39
     float u1 = draw<COUNT>(rng, c);
     u1 = fminf_(u1, 1.0f - kEps);
     float u2 = draw<COUNT>(rng, c);
@@ -62,7 +69,7 @@ PT_DEV void cosine_sample_f(Rng& rng, V3 base, V3& wo, V3& f, float& pdf, Ctr& c
     float phi = 2.0f * kPi * u2;
     float sn, cs; sincos_(phi, sn, cs);
     wo = v3(r * cs, r * sn, __builtin_sqrtf(1.0f - u1));
-    f = cosine_f(base);
+    f = fPre ? ld3(fPre) : cosine_f(base);
     pdf = cosine_pdf(wo);
 }
 
@@ -234,7 +241,7 @@ PT_DEV void material_inputs(const PMat& m, const float4* tex, float uvx, float u
 PT_DEV V3 f_eval(const PMat& m, const float4* tex, V3 wi, V3 wo, float etaI, float uvx, float uvy) {
     V3 albedo; float trans;
     material_inputs(m, tex, uvx, uvy, true, albedo, trans);
-    if (m.type == 0) return cosine_f(ld3(m.albedo));
+    if (m.type == 0) return ld3(m.albedoOverPi);                 // cosine_f(mat.albedo) = albedo / PI, divided once at scene set-up (same IEEE division)
     if (m.type == 1) return microfacet_metal_f(ld3(m.eta), ld3(m.k), m.roughness, -wi, wo);
     if (m.type == 4) return leaf_f(albedo, m.ior, etaI, m.roughness, trans, -wi, wo);
     if (m.type == 6) return v3(1.0f / fmaxf_(wo.z, kEps));           // mirror_f :59-63
@@ -258,7 +265,7 @@ template <bool COUNT>
 PT_DEV void sample_f_eval(Rng& rng, const PMat& m, const float4* tex, V3 wi, float etaI, bool backface, V3& wo, V3& f, float& pdf, float uvx, float uvy, Ctr& c) {
     V3 albedo; float trans;
     material_inputs(m, tex, uvx, uvy, true, albedo, trans);
-    if (m.type == 0) cosine_sample_f<COUNT>(rng, albedo, wo, f, pdf, c);
+    if (m.type == 0) cosine_sample_f<COUNT>(rng, albedo, wo, f, pdf, c, (m.flags & kMatHasTexture) ? nullptr : m.albedoOverPi);
     else if (m.type == 1) {                                                                       // :160-180
         V3 w = -wi;
         V3 h = ggx_sample_h<COUNT>(rng, m.roughness, c);

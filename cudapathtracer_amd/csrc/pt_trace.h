@@ -25,6 +25,7 @@ namespace pt {
 
 struct Ctr {
     uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters;
+    uint32_t gnodes;    // internal-node fetches that went to global memory (index beyond the LDS scene cache): the L1 line-rate roofline of bench.py
 #ifdef PT_UTIL
     uint32_t u[8];      // diagnostic build (tools/lane_util.py): {wave-level, lane-level} steps of the node / triangle loops, closest then shadow
 #endif
@@ -79,6 +80,22 @@ struct Stack {
 
 struct Hit { float t, u, v; int32_t tri; int32_t material; };
 
+// 1 / direction per component (aabbIntersect recomputes it per box, integratorUtilities.cuh:50-55): the exact fast
+// reciprocal when all three components are in its proven range — one branch per ray — else the IEEE divisions (a
+// component of 0 gives the reference's +-inf, a denormal-range one its huge quotient).
+PT_DEV V3 inv3(V3 d) {
+#if PT_FAST_RCP
+    const float lo = fminf_(fminf_(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    const float hi = fmaxf_(fmaxf_(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+    if (lo >= 1e-12f && hi <= 1.0e30f) {                 // (NaN components fail the comparisons and take the IEEE path)
+        const float rx = __builtin_amdgcn_rcpf(d.x), ry = __builtin_amdgcn_rcpf(d.y), rz = __builtin_amdgcn_rcpf(d.z);
+        return v3(__builtin_fmaf(rx, __builtin_fmaf(-d.x, rx, 1.0f), rx), __builtin_fmaf(ry, __builtin_fmaf(-d.y, ry, 1.0f), ry),
+                  __builtin_fmaf(rz, __builtin_fmaf(-d.z, rz, 1.0f), rz));
+    }
+#endif
+    return v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
 // aabbIntersect (integratorUtilities.cuh:44-82) with a hoisted reciprocal direction.
 PT_DEV bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, V3 o, V3 inv, float& tmin) {
     float tx1 = (mnx - o.x) * inv.x, tx2 = (mxx - o.x) * inv.x;
@@ -99,7 +116,7 @@ PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u,
     V3 h = cross(d, e2);
     float a = dot(h, e1);
     if (__builtin_fabsf(a) < 1e-12f) return false;
-    float f = 1.0f / a;                    // == (float)(1.0 / (double)a), DESIGN.md §4
+    float f = rcp_exact(a);                 // == 1.0f / a == (float)(1.0 / (double)a), DESIGN.md §4
     V3 s = o - v0;
     u = f * dot(s, h);
     V3 q = cross(s, e1);
@@ -172,7 +189,7 @@ PT_DEV int lanes_here() { return __builtin_popcountll(__builtin_amdgcn_ballot_w6
 template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
 PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c, float cullT = 0.0f) {
     NodeData n = load_node<ONCHIP>(S, C, cur);
-    if (COUNT) { c.pops++; c.boxes += 2; }
+    if (COUNT) { c.pops++; c.boxes += 2; if (!ONCHIP && cur >= C.nNodes) c.gnodes++; }
     float tL, tR;
     bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
     bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);
@@ -191,7 +208,7 @@ PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V
 // BVHSceneIntersect (integratorUtilities.cuh:84-186), max_t as the reference's 999999.
 template <bool COUNT, int N, bool ONCHIP, bool CULL>
 PT_DEV void trace_closest_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c) {
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv = inv3(d);
     float min_t = 3.402823466e+38f;
     hit.tri = -1;
     st.sp = 0;
@@ -227,7 +244,7 @@ PT_DEV void trace_closest_plain(const DeviceScene& S, const SceneCache& C, V3 o,
 template <bool COUNT, int N, bool ONCHIP, bool CULL>
 PT_DEV void trace_closest_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, Keep k) {
     typedef LoopExit<ONCHIP> X;
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv = inv3(d);
     float min_t = 3.402823466e+38f;
     hit.tri = -1;
     st.sp = 0;
@@ -290,7 +307,7 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
 template <bool COUNT, int N, bool ONCHIP, bool CULL>
 PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv = inv3(d);
     V3 thr = v3(1.0f);
     st.sp = 0;
     int32_t cur = S.rootRef;
@@ -333,7 +350,7 @@ PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3
 template <bool COUNT, int N, bool ONCHIP, bool CULL>
 PT_DEV V3 trace_shadow_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k) {
     typedef LoopExit<ONCHIP> X;
-    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 inv = inv3(d);
     V3 thr = v3(1.0f);
     st.sp = 0;
     int32_t cur = S.rootRef;
@@ -430,7 +447,7 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     const int lane = (int)(threadIdx.x & 63u);
     lds_i32* W = st.lds - lane;                                  // the wave's 16 x 64 words; field f of lane l at W[f * 64 + l]
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const V3 inv = inv3(d);
     // 1. lockstep node walk
     uint64_t tm = 0ull;
     if (S.rootRef < 0) tm = active ? ~0ull >> (64 - S.nTris) : 0ull;      // the root is the only leaf
@@ -574,7 +591,7 @@ struct Trav {
     template <bool COUNT>
     PT_DEV void start(const DeviceScene& S, Stack<N>& st, V3 o_, V3 d_, float maxt, bool shadow_, Ctr& c) {
         o = o_; d = d_;
-        inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        inv = inv3(d);
         max_t = maxt; min_t = 3.402823466e+38f;
         cur = S.rootRef; shadow = shadow_;
         hit.tri = -1; hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f; hit.material = 0;
@@ -648,8 +665,8 @@ PT_DEV void trace_pair(const DeviceScene& S, const SceneCache& C, Stack<N>& st, 
     h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     thr = v3(1.0f);
     if (!hasShadow && !hasExt) return;
-    const V3 invS = v3(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z);
-    const V3 invE = v3(1.0f / ed.x, 1.0f / ed.y, 1.0f / ed.z);
+    const V3 invS = inv3(sd);
+    const V3 invE = inv3(ed);
     if (COUNT) { if (hasShadow) c.raysShadow++; if (hasExt) c.raysClosest++; }
     bool isShadow = hasShadow;
     V3 o = isShadow ? so : eo, d = isShadow ? sd : ed, inv = isShadow ? invS : invE;
@@ -729,7 +746,7 @@ PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasS
     thr = v3(1.0f);
     if (COUNT) { if (hasShadow) c.raysShadow++; if (hasExt) c.raysClosest++; }
     r.o = hasShadow ? so : eo; r.d = hasShadow ? sd : ed;
-    r.inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    r.inv = inv3(r.d);
     r.max_t = hasShadow ? smaxt : 999999.0f;
     r.min_t = 3.402823466e+38f;
     r.cur = S.rootRef;
@@ -764,7 +781,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
         if (cur == kRefNone) {
             if (isShadow && extFollows) {               // shadow ray done: start this lane's extension ray
                 isShadow = false; extFollows = false;
-                o = eo; d = ed; inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); max_t = 999999.0f;
+                o = eo; d = ed; inv = inv3(d); max_t = 999999.0f;
                 cur = S.rootRef; st.sp = 0;
                 continue;
             }

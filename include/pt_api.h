@@ -208,7 +208,9 @@ int pt_set_culling(pt_scene* scene, int on);
  * Returns 0, or < 0 for an unknown name / a value out of range. */
 int pt_set_option(pt_scene* scene, const char* name, int value);
 int pt_get_option(pt_scene* scene, const char* name, int* value);
-/* Diagnostic builds only, eight sums since the last pt_reset_counters; zeros in a normal build.
+/* Eight more sums since the last pt_reset_counters. Normal build: out8[0] = internal-node fetches of counting launches
+ * that went to global memory (node index beyond the LDS scene cache) — with tri_tests, the L1 line-access count behind
+ * bench.py's roofline for scenes in HBM; the rest zero. Diagnostic builds:
  * -DPT_STAMPS: s_memtime spent in regeneration, closest-hit traversal, bounce logic (incl. the shadow ray), then the
  * sum of wave lifetimes, ~(earliest start) and the latest end on the 100 MHz wall clock, 0, 0 (tools/stamps.py).
  * -DPT_UTIL (counting launches): {trips of a wave, trips summed over its lanes} through the node loop and the

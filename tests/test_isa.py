@@ -20,11 +20,19 @@ CSRC = os.path.join(ROOT, "cudapathtracer_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("isa") / "pt_kernels.s")
+    """Device code of the two translation units that instantiate the megakernel, with the Makefile's flags."""
+    d = tmp_path_factory.mktemp("isa")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
-    subprocess.check_call(["hipcc"] + flags + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "pt_kernels.hip")],
-                          stderr=subprocess.DEVNULL)
-    return open(out).read()
+    procs = []
+    for tu, extra in (("pt_mk_lds", ["-fno-slp-vectorize"]), ("pt_mk_hbm", [])):
+        out = str(d / (tu + ".s"))
+        procs.append((out, subprocess.Popen(["hipcc"] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, tu + ".hip")],
+                                            stderr=subprocess.DEVNULL)))
+    text = ""
+    for out, pr in procs:
+        assert pr.wait() == 0, out
+        text += open(out).read()
+    return text
 
 
 def _functions(text):
@@ -42,7 +50,7 @@ def _is_counting(name):
 
 def test_state_stores_are_waited_for_before_the_queue_entry(isa):
     fns = _functions(isa)
-    assert len(fns) >= 30, sorted(fns)
+    assert len(fns) >= 28, sorted(fns)
     checked = 0
     for name, body in fns.items():
         lines = [ln.strip() for ln in body.split("\n")]

@@ -101,5 +101,11 @@ def test_multi_render_full_frame_on_a_scene_in_hbm(api, gpu_ready, scene_dir):
     full, _ = api.Scene(hs).render(hs.camera(), 1920, 1080, 2, 6)
     ms = api.MultiScene(hs, 8, device_ids=[0] * 8)
     got = ms.render(hs.camera(), 1920, 1080, 2, 6)
+    if not np.array_equal(got.view(np.uint32), full.view(np.uint32)):       # say WHICH ranks' tiles differ before failing
+        bad = np.argwhere((got.view(np.uint32) != full.view(np.uint32)).any(axis=-1))
+        tiles = (bad[:, 0] // 8) * 240 + bad[:, 1] // 8
+        again, _ = api.Scene(hs).render(hs.camera(), 1920, 1080, 2, 6)
+        print("differing pixels %d, tiles %d, ranks %s, single-device frame repeatable %s, stats %s" %
+              (len(bad), len(set(tiles.tolist())), sorted(set((tiles % 8).tolist())), np.array_equal(again.view(np.uint32), full.view(np.uint32)), ms.stats))
     assert_bits_equal(got, full, "8 ranks, 1080p")
     assert ms.stats["gather"] == "peer_copy" and len(ms.stats["kernel_ms"]) == 8

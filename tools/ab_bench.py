@@ -18,12 +18,13 @@ for r in range(a.rounds):
         base, _, opt = n.partition("+")              # "v3+defer" = lib_v3.so with PT_DEFER_SHADOW=1
         lib = os.path.join(ROOT, "cudapathtracer_amd", "csrc", "variants", "lib_%s.so" % base)
         env = dict(os.environ, PT_LIB_PATH=lib)
+        extra = []
         if opt == "defer":
-            env["PT_DEFER_SHADOW"] = "1"
+            extra = ["--opt", "defer_shadow=1"]
         if a.golden and r == 0:
             t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k", "golden or fresh or deep"], cwd=ROOT, env=env, capture_output=True, text=True)
             print(n, "parity:", t.stdout.strip().splitlines()[-1] if t.stdout.strip() else t.stderr[-300:], flush=True)
-        p = subprocess.run([sys.executable, "bench.py", "--spp", str(a.spp), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", a.workload],
+        p = subprocess.run([sys.executable, "bench.py", "--spp", str(a.spp), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", a.workload] + extra,
                            cwd=ROOT, env=env, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         if not line:
