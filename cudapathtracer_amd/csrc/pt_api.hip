@@ -69,6 +69,7 @@ struct pt_scene {
     bool sliceAlways = true;     // "slice_always" 0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // "waves_hbm" 0: scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
     int nodeKeep = 8, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
+    int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
     bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
@@ -520,6 +521,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cull = (s->cull && hbm) ? 1 : 0;
     P.refill = (s->refill && !deferred && !P.cull && !s->armless && (!onchip || s->refill == 2)) ? 1 : 0;   // 2: also the LDS-resident kernel (A/B)
     P.refillKeep = s->refillKeep;
+    P.spec = s->spec;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
     P.flat = (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) ? 1 : 0;
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
@@ -707,7 +709,7 @@ struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
     {"flat", 0, 1}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
-    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -737,6 +739,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 12: s->persistent = v != 0; break;
         case 13: s->xcdBands = v != 0; break;
         case 14: s->cull = v != 0; break;
+        case 15: s->spec = v; break;
     }
     return 0;
 }
@@ -759,6 +762,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 12: *out = s->persistent; break;
         case 13: *out = s->xcdBands; break;
         case 14: *out = s->cull; break;
+        case 15: *out = s->spec; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

@@ -218,7 +218,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
     RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
-    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
+    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.pend = kRefNone; rs.flags = 0u;
 #ifdef PT_STAMPS
     unsigned long long stamp[4] = {0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -306,7 +306,14 @@ PT_DEV void megakernel_body(const KParams& P) {
             PT_STAMP(2);
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
+#if PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
+            if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+            else trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+#elif PT_SPEC == 1
+            trace_resume_spec<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+#else
             trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+#endif
             PT_STAMP(1);
             continue;
         }

@@ -15,6 +15,9 @@ namespace pt {
 #ifndef PT_CACHE_BYTES
 #define PT_CACHE_BYTES 12288      // LDS bytes per workgroup for the scene cache (top PNodes / all PTris)
 #endif
+#ifndef PT_SPEC
+#define PT_SPEC 0                 // resumable traversal of the REFILL kernels: 0 trace_resume, 1 trace_resume_spec (speculative descent), 2 both (A/B)
+#endif
 constexpr int kStackLds = PT_STACK_LDS;
 #ifndef PT_WAVES_HBM
 #define PT_WAVES_HBM 6             // waves per SIMD of the instantiation for scenes that do not fit the LDS cache (0 = use the 4-wave kernel)
@@ -57,6 +60,7 @@ struct KParams {
     int flat;                      // 1: the FLAT instantiation (pt_trace.h: trace_closest_flat) — LDS-resident scenes with at most 64 internal nodes / 64 triangles
     int refill;                    // 1: the REFILL instantiation (pt_trace.h: trace_resume) — finished lanes shade and come back while the rest keep tracing
     int refillKeep;                // the wave leaves the traversal when no more than busy * refillKeep / 16 lanes are still tracing
+    int spec;                      // REFILL kernels: 0 trace_resume, 1 speculative descent for closest-hit rays (pt_trace.h: trace_resume_spec), 2 also for shadow rays
     int wgWaves;                   // waves per workgroup of this launch (4, or kWgWavesHbm for megakernel_hbm)
     int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels

@@ -735,6 +735,7 @@ struct RayState {
     V3 o, d, inv;
     float max_t, min_t;
     int32_t cur;
+    int32_t pend;                      // trace_resume_spec: the one postponed leaf (kRefNone = none)
     uint32_t flags;                    // kRayBusy | kRayShadow | kRayExtFollows
 };
 constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u;
@@ -750,6 +751,7 @@ PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasS
     r.max_t = hasShadow ? smaxt : 999999.0f;
     r.min_t = 3.402823466e+38f;
     r.cur = S.rootRef;
+    r.pend = kRefNone;
     r.flags = kRayBusy | (hasShadow ? kRayShadow : 0u) | ((hasShadow && hasExt) ? kRayExtFollows : 0u);
     st.sp = 0;
 }
@@ -830,6 +832,112 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
         cur = (!occluded && st.sp > 0) ? st.template pop<ONCHIP>() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
     }
     r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur;
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
+    if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
+}
+
+// ---- speculative descent (scenes in HBM) ---------------------------------------------------------
+// Without culling the set of leaves a ray visits does not depend on what it hits, so a lane that reaches a leaf need not
+// test it at once: it POSTPONES the leaf (one slot, FIFO) and keeps descending with the wave; the wave switches to the
+// triangle loop when too few lanes can still descend, and there every lane that holds a postponed leaf tests it. Leaves are
+// tested in the order they were reached, so the strict `t < min_t` tie rule sees the reference's order; per ray the visits,
+// tests and counters are those of trace_resume. What changes is how many lanes a trip through the node loop carries: on
+// the 263 k-triangle scene a ray takes ~6 node steps between two leaves, and a lane that waits at its leaf for the others
+// is idle for those trips (26 of 64 lanes per trip with trace_resume).
+// MEASURED (profiles/r02_ab_spec.log): 263 k triangles 861.3 -> 861.4 ms, 82 k triangles 254.7 -> 251.6 ms (+1.2 %) — the
+// trips saved are paid for by the ballot and the postponement logic in every trip, and this kernel is not bound by the
+// lanes of its node loop alone. Not the default: build with -DPT_SPEC=1 to reproduce.
+// A shadow ray that the postponed leaf will occlude descends a few nodes in vain; `specShadow` = false keeps shadow rays
+// strictly in the reference's order (the counting kernels need that: their node counters are compared with the oracle's).
+constexpr int32_t kRefHold = (int32_t)0x80000001;      // "the next ref is popped after the pending leaf" (no speculation for this ray)
+
+template <bool COUNT, int N, bool ONCHIP>
+PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
+                              V3& thr, Hit& h, Ctr& c, Keep k, bool specShadow) {
+    typedef LoopExit<ONCHIP> X;
+    if (!(r.flags & kRayBusy)) return;
+    V3 o = r.o, d = r.d, inv = r.inv;
+    float max_t = r.max_t, min_t = r.min_t;
+    int32_t cur = r.cur, pend = r.pend;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    while (true) {
+        const int active = lanes_here();
+        if (active <= minBusy) break;
+        // ---- node phase: descend while enough lanes can ----
+        const int keepN = (active * k.node) >> 4;
+        while (true) {
+            if (pend == kRefNone && cur < 0 && cur != kRefNone && cur != kRefHold) {       // reached a leaf: postpone it
+                pend = cur;
+                const bool spec = !isShadow || (specShadow && !COUNT);
+                cur = spec ? (st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone) : kRefHold;
+            }
+            const bool can = cur >= 0;
+            const int nCan = __builtin_popcountll(__builtin_amdgcn_ballot_w64(can));
+            if (nCan == 0 || (X::node && nCan <= keepN)) break;
+            if (can) {
+                PT_UTIL_STEP(c, 0);
+                cur = descend<COUNT, N, ONCHIP>(S, C, cur, o, inv, st, c);
+            }
+        }
+        // ---- triangle phase: the postponed leaves ----
+        if (pend != kRefNone) {
+            int32_t ti = ~pend;
+            uint32_t idx;
+            bool occluded = false, more;
+            int keepT = 0;
+            if (X::tri) keepT = (lanes_here() * k.tri) >> 4;
+            do {
+                TriData q = load_tri<ONCHIP>(S, C, ti);
+                idx = f2u(q.e.y);
+                if (COUNT) c.tris++;
+                PT_UTIL_STEP(c, 2);
+                float t, u, v;
+                bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+                if (isShadow) {
+                    if (ok && (t < max_t)) {
+                        uint32_t flags = f2u(q.e.w);
+                        if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                        // MAT_LEAF (integratorUtilities.cuh:218-239)
+                        const PMat& m = S.mats[f2i(q.e.z)];
+                        const PAttr& at = S.attrs[idx & 0x7fffffffu];
+                        float bz = 1.0f - u - v;
+                        V3 n = ld3(at.n0) * bz + ld3(at.n1) * u + ld3(at.n2) * v;
+                        float cosTheta = __builtin_fabsf(dot(d, normalize(n)));
+                        float F = schlick_fresnel(cosTheta, 1.0f, m.ior);
+                        V3 sc = ld3(m.albedo) * m.transmission * (1.0f - F);
+                        thr = thr * sc;
+                        if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); occluded = true; break; }
+                    }
+                } else if (ok && (t < min_t) && (t < max_t)) {
+                    min_t = t;
+                    h.t = t; h.u = u; h.v = v;
+                    h.tri = (int32_t)(idx & 0x7fffffffu);
+                    h.material = f2i(q.e.z);
+                }
+                ti++;
+                more = !(idx & 0x80000000u);
+                if (X::tri && more && lanes_here() <= keepT) break;
+            } while (more);
+            if (X::tri && !occluded && more) pend = ~ti;                               // the rest of this leaf next time round
+            else {
+                if (COUNT) c.pops++;
+                pend = kRefNone;
+                if (occluded) { cur = kRefNone; st.sp = 0; }                             // BVHShadowRay returns at the first opaque hit
+                else if (cur == kRefHold) cur = st.sp > 0 ? st.template pop<ONCHIP>() : kRefNone;
+            }
+        }
+        if (cur == kRefNone && pend == kRefNone) {                                      // this ray is through
+            if (isShadow && extFollows) {                                               // start the lane's extension ray
+                isShadow = false; extFollows = false;
+                o = eo; d = ed; inv = inv3(d); max_t = 999999.0f;
+                cur = S.rootRef; st.sp = 0;
+                continue;
+            }
+            busy = false;
+            break;
+        }
+    }
+    r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur; r.pend = pend;
     r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }

@@ -194,17 +194,19 @@ def test_time_sliced_tile_queue(api, gpu_ready, sched):
         sc.close()
 
 
-@pytest.mark.parametrize("knobs", [("0", "4", "0", "0", "2", "0", "512"),      # everything off: a wave stays in each loop until its last lane
-                                   ("0", "4", "15", "15", "2", "0", "4"),     # loops left as soon as ONE lane is through, shadow rays traced in the bounce
-                                   ("1", "1", "8", "8", "2", "0", "4"),       # production shape, traversal left only for the last sixteenth
-                                   ("1", "15", "15", "1", "0", "0", "8"),     # 4-wave kernel; traversal and node loop left at the first finished lane
-                                   ("1", "4", "1", "15", "2", "0", "0"),      # no time slices
-                                   ("2", "4", "8", "8", "1", "1", "4")])      # REFILL also for the LDS-resident instantiation (A/B only)
+@pytest.mark.parametrize("knobs", [("0", "4", "0", "0", "2", "0", "512", "0"),      # everything off: a wave stays in each loop until its last lane
+                                   ("0", "4", "15", "15", "2", "0", "4", "2"),     # loops left as soon as ONE lane is through, shadow rays traced in the bounce
+                                   ("1", "1", "8", "8", "2", "0", "4", "2"),       # production shape, traversal left only for the last sixteenth
+                                   ("1", "15", "15", "1", "0", "0", "8", "1"),     # 4-wave kernel; traversal and node loop left at the first finished lane; speculation for closest-hit rays only
+                                   ("1", "4", "1", "15", "2", "0", "0", "2"),      # no time slices
+                                   ("1", "4", "8", "8", "2", "0", "4", "0"),       # resumable traversal without speculative descent
+                                   ("1", "4", "0", "0", "2", "0", "16", "2"),      # speculative descent with the loop exits off
+                                   ("2", "4", "8", "8", "1", "1", "4", "2")])      # REFILL also for the LDS-resident instantiation (A/B only)
 def test_loop_exits_and_refill(api, gpu_ready, knobs):
     """pt_trace.h LoopExit / trace_resume: when a wave leaves its node loop, its triangle loop or the traversal
     (lanes that are through go on, the others resume later) is scheduling, not arithmetic — golden colours AND the
     per-pixel work counters bit for bit at every threshold, on all kernels (timed and counting instantiations)."""
-    opts = {k: int(v) for k, v in zip(("refill", "refill_keep", "node_keep", "tri_keep", "waves_hbm", "onchip", "slice_iters"), knobs)}
+    opts = {k: int(v) for k, v in zip(("refill", "refill_keep", "node_keep", "tri_keep", "waves_hbm", "onchip", "slice_iters", "spec"), knobs)}
     opts["sched_mask"] = 3
     used = []
     for case in CASES:
@@ -633,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
