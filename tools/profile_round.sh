@@ -1,0 +1,32 @@
+#!/bin/bash
+# The measurements one round commits under profiles/ (run on the GPU box): tools/profile_round.sh TAG
+#   1. PMC passes (tools/pmc_passes.sh: counters in their own runs, --kernel-trace only) for the headline workload and the
+#      two secondary workloads -> entries of profiles/roofline_inputs.json (tools/roofline.py collect)
+#   2. rocprofv3 --kernel-trace --stats of bench.py -> per-kernel average durations
+#   3. bench.py itself (after the inputs exist, so that its roofline block is complete) -> the bench line
+set -e
+tag=${1:-rXX}
+out=gpurun_out/$tag
+mkdir -p $out
+SQ="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU"
+run_pmc() {  # workload spp name
+  bash tools/pmc_passes.sh $out/pmc_$3 $1 $2 "$SQ" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"
+  ms=$(python - <<PY
+import csv,glob
+rows=[r for f in glob.glob("$out/pmc_$3/pass2/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
+t=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6 for r in rows if "megakernel" in r["Kernel_Name"] and "<0, false" in r["Kernel_Name"]]
+print("%.3f" % t[-1])
+PY
+)
+  python tools/roofline.py collect $out/pmc_$3 $1 $2 --kernel-ms $ms > $out/entry_$3.json
+  python tools/roofline.py add $out/entry_$3.json
+  echo "pmc $3 done (kernel under the profiler $ms ms)"
+}
+run_pmc cornell_1920x1080_1024spp_depth8_mis 1024 cornell
+run_pmc atrium262k_1920x1080_4096spp_depth16_mis 32 atrium_spp32
+run_pmc blob82k_1920x1080_1024spp_depth8_mis 1024 blob
+cp profiles/roofline_inputs.json $out/roofline_inputs.json
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/stats.log 2>&1 )
+python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err
+python tools/roofline.py check $out/bench.json
+tail -c 400 $out/bench.json
