@@ -72,8 +72,9 @@ struct pt_scene {
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
+    bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
-    int lastLaunchFlat = 0;
+    int lastLaunchFlat = 0, lastLaunchSimple = 0;
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // "waves_hbm" 2: ... and the 6-wave kernel whatever the tile count (tests)
@@ -285,6 +286,18 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         p.albedoOverPi[0] = m.albedo.x / kPi; p.albedoOverPi[1] = m.albedo.y / kPi; p.albedoOverPi[2] = m.albedo.z / kPi;   // cosine_f, reflectors.cuh:10-13
     }
 
+    // SIMPLE scenes (pt_path.h): every triangle's material an untextured MAT_DIFFUSE that is neither boundary nor specular,
+    // in air (material 0) that does not absorb — then the medium stack never changes and the dispatchers have one arm.
+    {
+        bool simple = d->materials[0].absorption.x == 0.0f && d->materials[0].absorption.y == 0.0f && d->materials[0].absorption.z == 0.0f;
+        for (int i = 0; i < nT && simple; i++) {
+            const int id = d->triangles[i].materialID;
+            if (id < 0 || id >= d->n_materials) { simple = false; break; }
+            const pt_material& m = d->materials[id];
+            simple = m.type == PT_MAT_DIFFUSE && !m.hasTexture && !m.hasTransMap && !m.boundary && !m.isSpecular;
+        }
+        s->simpleOk = simple;
+    }
     if (!onDevice) {
         if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
         if (int r = upload(s->tris, tris.data(), tris.size() * sizeof(PTri))) return r;
@@ -524,7 +537,9 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.spec = s->spec;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
     P.flat = (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) ? 1 : 0;
+    P.simple = ((P.flat || (hbm && P.refill)) && s->simpleOk && s->simpleWanted) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
+    s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -709,7 +724,7 @@ struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
     {"flat", 0, 1}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
-    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -740,6 +755,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 13: s->xcdBands = v != 0; break;
         case 14: s->cull = v != 0; break;
         case 15: s->spec = v; break;
+        case 16: s->simpleWanted = v != 0; break;
     }
     return 0;
 }
@@ -763,6 +779,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 13: *out = s->xcdBands; break;
         case 14: *out = s->cull; break;
         case 15: *out = s->spec; break;
+        case 16: *out = s->simpleWanted; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;
@@ -774,7 +791,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

@@ -137,7 +137,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false>
 PT_DEV void megakernel_body(const KParams& P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
@@ -291,7 +291,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             if (!(rs.flags & kRayBusy)) {
                 apply_pending(ps, thr, acc);
                 if (ps.flags & kInPath) {
-                    bool done = path_bounce<INTEG, COUNT, true>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+                    bool done = path_bounce<INTEG, COUNT, true, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
                     if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
                     if (done) path_finish(ps, acc, true);
                 }
@@ -319,7 +319,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         }
         if (DEFER) apply_pending(ps, thr, acc);
         if (ps.flags & kInPath) {
-            bool done = path_bounce<INTEG, COUNT, DEFER>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+            bool done = path_bounce<INTEG, COUNT, DEFER, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
             if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
             if (done) path_finish(ps, acc, DEFER);
         }
@@ -408,16 +408,16 @@ PT_DEV void megakernel_body(const KParams& P) {
 // 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
 // cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
 // included (5: +10 %, 7-8: no better). Both run the same body.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false, bool SIMPLE = false>
 __global__ void __launch_bounds__(256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
 #endif
-megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT>(P); }
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT, SIMPLE>(P); }
 
-template <int INTEG, bool COUNT, bool CULL, bool REFILL>
+template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
-megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL>(P); }
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE>(P); }
 
 
 }  // namespace pt

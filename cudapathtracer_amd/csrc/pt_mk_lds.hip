@@ -9,6 +9,7 @@ namespace pt {
 hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, dim3 grid, dim3 block, unsigned lds, hipStream_t stream) {
 #define PT_LAUNCH(I, C, RF, FL) hipLaunchKernelGGL((megakernel<I, C, false, true, RF, FL>), grid, block, lds, stream, P)
 #define PT_PICK(I) do { if (P.refill) { if (count) PT_LAUNCH(I, true, true, false); else PT_LAUNCH(I, false, true, false); } \
+                        else if (P.flat && !count && P.simple) hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true>), grid, block, lds, stream, P); \
                         else if (P.flat && !count) PT_LAUNCH(I, false, false, true); \
                         else if (count) PT_LAUNCH(I, true, false, false); \
                         else PT_LAUNCH(I, false, false, false); } while (0)

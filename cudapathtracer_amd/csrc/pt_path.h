@@ -139,7 +139,11 @@ PT_DEV bool path_exhausted(PathState& ps, int maxDepth) {
 // offset, which keeps the whole struct in scratch memory.)
 struct NeeRecord { V3 so, sd; float smaxt; V3 neeRaw, neeBeta; float neeW; };
 
-template <int INTEG, bool COUNT, bool DEFER, class MS, class ShadowFn>
+// SIMPLE (chosen per scene by the host, pt_api.hip: scene_simple): every triangle's material is an untextured MAT_DIFFUSE
+// that is neither a boundary nor specular, and material 0 (the air every path starts in) does not absorb — the reference's
+// own Cornell configuration. Then the medium stack only ever holds air, every hit is a true hit, the three dispatchers
+// have one arm each, and all of that is known at compile time: same values, a third of the code.
+template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE, class MS, class ShadowFn>
 PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, V3& Li, V3& prevPoint, V3& woLocal,
                         float& pdf, float& etaI, float& etaT, int& depth, int& msTop, uint32_t& flags, NeeRecord& nr,
                         MS& ms, const Hit& h, int maxDepth, int useMIS, ShadowFn shadow, Ctr& c) {
@@ -157,7 +161,8 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         V3 toSurface = to_local(d, frame);
         V3 f = v3(0.0f), toNext = v3(0.0f);
         float p = 0.0f;
-        sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
+        if (SIMPLE) cosine_sample_f<COUNT>(rng, ld3(m.albedo), toNext, f, p, c, m.albedoOverPi);
+        else sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
         if (p <= 0.0f || dot(f, f) < kEps) return true;
         Li = Li + hi.emission * beta;
         beta = beta * ((f * __builtin_fabsf(toNext.z)) / p);
@@ -170,45 +175,46 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
     // ---- Li_unidirectional, deviceCode.cu:332-537 ----
     const Onb frame = onb_of(hi.normal);                 // toLocal / toWorld of this bounce all use the hit's normal
     V3 wiLocal = to_local(d, frame);
-    const bool isSpecular = (m.flags & kMatSpecular) != 0;
-    bool trueHit = true;
-    int minPriorID = ms.get(0);
-    int minPrior = S.mats[minPriorID].priority;
-    for (int i = 1; i < msTop; i++) {
-        int id = ms.get(i);
-        int pr = S.mats[id].priority;
-        if (pr < minPrior) { minPrior = pr; minPriorID = id; }
-    }
-    const PMat& dom = S.mats[minPriorID];
-    // Beer-Lambert, deviceCode.cu:362-368. A medium that does not absorb (air, plain glass: absorption exactly 0) gives
-    // exp(-+0) = 1.0f exactly in this arithmetic and beta * 1.0f = beta bit for bit, so the three exps are skipped.
-    if (hi.dist > kEps && !(dom.absorption[0] == 0.0f && dom.absorption[1] == 0.0f && dom.absorption[2] == 0.0f)) {
-        V3 att = v3(exp_(-dom.absorption[0] * hi.dist), exp_(-dom.absorption[1] * hi.dist), exp_(-dom.absorption[2] * hi.dist));
-        beta = beta * att;
-    }
-    if (m.flags & kMatBoundary) {
-        if (m.priority <= minPrior) {
-            if (m.type == 2) {
-                etaI = dom.ior;
-                if (!hi.backface) etaT = m.ior;
-                else if (msTop == 1) etaT = 1.0f;
-                else {
-                    int mp = 99, second = ms.get(0);
-                    for (int i = 0; i < msTop; i++) {
-                        int id = ms.get(i);
-                        int pr = S.mats[id].priority;
-                        if (pr) { if (mp > pr && id != hi.material) { second = id; mp = pr; } }
-                    }
-                    etaT = S.mats[second].ior;
-                }
-            }
-        } else {
-            trueHit = false;
-            if (!hi.backface) { if (msTop < 16) { ms.set(msTop, hi.material); msTop++; } }
-            else medium_remove(ms, msTop, hi.material);
+    bool isSpecular = false, trueHit = true;
+    if (!SIMPLE) {
+        isSpecular = (m.flags & kMatSpecular) != 0;
+        int minPriorID = ms.get(0);
+        int minPrior = S.mats[minPriorID].priority;
+        for (int i = 1; i < msTop; i++) {
+            int id = ms.get(i);
+            int pr = S.mats[id].priority;
+            if (pr < minPrior) { minPrior = pr; minPriorID = id; }
         }
-    } else etaI = dom.ior;
-
+        const PMat& dom = S.mats[minPriorID];
+        // Beer-Lambert, deviceCode.cu:362-368. A medium that does not absorb (air, plain glass: absorption exactly 0) gives
+        // exp(-+0) = 1.0f exactly in this arithmetic and beta * 1.0f = beta bit for bit, so the three exps are skipped.
+        if (hi.dist > kEps && !(dom.absorption[0] == 0.0f && dom.absorption[1] == 0.0f && dom.absorption[2] == 0.0f)) {
+            V3 att = v3(exp_(-dom.absorption[0] * hi.dist), exp_(-dom.absorption[1] * hi.dist), exp_(-dom.absorption[2] * hi.dist));
+            beta = beta * att;
+        }
+        if (m.flags & kMatBoundary) {
+            if (m.priority <= minPrior) {
+                if (m.type == 2) {
+                    etaI = dom.ior;
+                    if (!hi.backface) etaT = m.ior;
+                    else if (msTop == 1) etaT = 1.0f;
+                    else {
+                        int mp = 99, second = ms.get(0);
+                        for (int i = 0; i < msTop; i++) {
+                            int id = ms.get(i);
+                            int pr = S.mats[id].priority;
+                            if (pr) { if (mp > pr && id != hi.material) { second = id; mp = pr; } }
+                        }
+                        etaT = S.mats[second].ior;
+                    }
+                }
+            } else {
+                trueHit = false;
+                if (!hi.backface) { if (msTop < 16) { ms.set(msTop, hi.material); msTop++; } }
+                else medium_remove(ms, msTop, hi.material);
+            }
+        } else etaI = dom.ior;
+    }
     bool done = false;
     if (trueHit) {
         float le2 = dot(hi.emission, hi.emission);
@@ -260,11 +266,12 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
                 float lightPdf = dist2 / (cosL * (float)S.nLights * L.area);
                 V3 wiL = to_local(wi, frame);
                 if (!DEFER) woLocal = wiL;
-                V3 f = f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
+                V3 f = SIMPLE ? ld3(m.albedoOverPi) : f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
                 V3 nee = ((f * ld3(L.emission)) * cosS) / lightPdf;
                 if (lightPdf > kEps) {
                     float pdfB = pdf;
-                    pdf_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy, pdfB);
+                    if (SIMPLE) pdfB = cosine_pdf(wiL);
+                    else pdf_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy, pdfB);
                     float wN = lightPdf * lightPdf / (pdfB * pdfB + lightPdf * lightPdf);
                     if (DEFER) {
                         nr.neeRaw = nee; nr.neeBeta = beta; nr.neeW = wN;
@@ -279,10 +286,11 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
             }
         }
         V3 f = v3(0.0f);
-        sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
+        if (SIMPLE) cosine_sample_f<COUNT>(rng, ld3(m.albedo), woLocal, f, pdf, c, m.albedoOverPi);
+        else sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
         V3 woWorld = to_world(woLocal, frame);
         pdf = fmaxf_(pdf, 0.01f);
-        if (woLocal.z < 0.0f) {
+        if (!SIMPLE && woLocal.z < 0.0f) {                 // (a cosine-sampled direction has z = sqrt(1 - u1) > 0: never taken when SIMPLE)
             if (!hi.backface) { if (msTop < 16) { ms.set(msTop, hi.material); msTop++; } }
             else medium_remove(ms, msTop, hi.material);
         }
@@ -310,7 +318,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
 }
 
 
-template <int INTEG, bool COUNT, bool DEFER, class MS, class ShadowFn>
+template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE = false, class MS, class ShadowFn>
 PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& h, int maxDepth, int useMIS, ShadowFn shadow, Ctr& c) {
     Rng rng = ps.rng;
     V3 o = ps.o, d = ps.d, beta = ps.beta, Li = ps.Li, prevPoint = ps.prevPoint, woLocal = ps.woLocal;
@@ -319,7 +327,7 @@ PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& 
     uint32_t flags = ps.flags;
     NeeRecord nr;
     nr.so = ps.so; nr.sd = ps.sd; nr.smaxt = ps.smaxt; nr.neeRaw = ps.neeRaw; nr.neeBeta = ps.neeBeta; nr.neeW = ps.neeW;
-    bool done = bounce_core<INTEG, COUNT, DEFER>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
+    bool done = bounce_core<INTEG, COUNT, DEFER, SIMPLE>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
                                                  ms, h, maxDepth, useMIS, shadow, c);
     ps.rng = rng;
     ps.o = o; ps.d = d; ps.beta = beta; ps.Li = Li; ps.prevPoint = prevPoint; ps.woLocal = woLocal;

@@ -180,7 +180,8 @@ float pt_last_kernel_ms(pt_scene* scene);
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
  * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing), bit 6 = it used the FLAT
- * closest-hit traversal (LDS-resident scenes with at most 64 nodes and triangles). For labelling measurements. */
+ * closest-hit traversal (LDS-resident scenes with at most 64 nodes and triangles), bit 7 = it used the SIMPLE bounce
+ * (every triangle an untextured MAT_DIFFUSE: one arm per dispatcher, no medium stack). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a
@@ -194,6 +195,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes (default 1)
+ *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
  *   "refill" 0|1|2        resumable traversal: off / scenes in HBM / also LDS-resident scenes (1)

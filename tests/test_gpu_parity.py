@@ -635,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -663,7 +663,7 @@ def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
     return col[y0:y1, x0:x1], (cnt[y0:y1, x0:x1] if counters else None)
 
 
-@pytest.mark.parametrize("mode", ["production", "plain_loops_4wave", "counted", "wavefront"])
+@pytest.mark.parametrize("mode", ["production", "generic_bounce", "plain_loops_4wave", "counted", "wavefront"])
 @pytest.mark.parametrize("case", window_cases())
 def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, mode):
     """BASELINE C3 / C4 / C5 geometry and depth at the 1080p camera, against the oracle: 64x64 windows of the 82 k-triangle
@@ -676,7 +676,7 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
     assert s["sha256"] == str(g["scene_sha256"])
     hs = api.HostScene(s["config"])
     w, h, spp, md = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"])
-    opts = {"production": {"waves_hbm": 2}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
+    opts = {"production": {"waves_hbm": 2}, "generic_bounce": {"waves_hbm": 2, "simple": 0}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
             "counted": {"waves_hbm": 2}, "wavefront": {}}[mode]
     sc = api.Scene(hs, options=opts)
     if mode == "wavefront":
@@ -687,9 +687,10 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
         assert_bits_equal(col, g["colors"][k], "%s window %d (%s)" % (case, k, mode))
         if mode == "counted":
             assert np.array_equal(cnt, g["counters"][k]), (case, k)
-        if mode == "production":
+        if mode in ("production", "generic_bounce"):
             fl = sc.flags()
             assert fl["hbm_kernel"] and fl["refill"] and not fl["onchip"] and not fl["culling"], fl
+            assert fl["simple"] == (mode == "production"), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
     x0, y0, x1, y1 = (int(v) for v in g["rects"][1])
     ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8)
     assert_bits_equal(ocol[y0:y1, x0:x1], g["colors"][1], "fixture == live oracle")
@@ -712,3 +713,34 @@ def test_fuzz_scene_depth16(api, oracle, gpu_ready, scene_dir):
             timed, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ)
             assert_bits_equal(timed, ocol, "fuzz depth 16, integrator %d, timed kernel" % integ)
         assert int(ocnt[..., 7].max()) > 16
+
+
+def test_simple_bounce_specialisation(api, oracle, gpu_ready, scene_dir):
+    """pt_path.h SIMPLE: scenes whose triangles are all untextured MAT_DIFFUSE (the reference's Cornell configuration, and
+    BASELINE's C2-C4 scenes) get a bounce with one arm per dispatcher and no medium stack. Same image as the generic
+    bounce and as the oracle; scenes with any other material, a texture, or absorbing 'air' must not qualify."""
+    from cudapathtracer_amd import scenes
+    for case in ("cornell32_mis", "cornell32_naive", "cornell64_mis"):
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        w, h = int(g["w"]), int(g["h"])
+        for simple in (1, 0):
+            sc = api.Scene(hs, options={"simple": simple})
+            col, _ = sc.render(hs.camera(), w, h, int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]))
+            assert sc.flags()["flat"] and sc.flags()["simple"] == bool(simple), sc.flags()
+            assert_bits_equal(col, g["colors"], "%s simple=%d" % (case, simple))
+    for case in ("mixed32_mis", "metal32_mis", "textured32_mis"):                      # mirror / glass / conductors / textures: generic bounce
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        sc = api.Scene(hs)
+        col, _ = sc.render(hs.camera(), int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]), integrator=int(g["integrator"]))
+        assert not sc.flags()["simple"], (case, sc.flags())
+        assert_bits_equal(col, g["colors"], case)
+    # a diffuse-only scene at depth 16 with long paths, both integrators, against a live oracle run
+    cfg = scenes.cornell(os.path.join(scene_dir, "simple16"), 40, 24, 6, 16, ceiling_light=True, name="simple16")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    for integ in (0, 2):
+        ocol, _, _ = osc.render(integrator=integ, threads=8)
+        col, _ = gs.render(hs.camera(), 40, 24, 6, 16, integrator=integ)
+        assert gs.flags()["simple"]
+        assert_bits_equal(col, ocol, "diffuse-only scene, depth 16, integrator %d" % integ)

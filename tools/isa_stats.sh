@@ -1,6 +1,6 @@
 #!/bin/bash
 # Static instruction mix of one megakernel instantiation (default: the headline FLAT kernel): tools/isa_stats.sh [mangled-name-substring] [extra hipcc flags]
-pat=${1:-megakernelILi0ELb0ELb0ELb1ELb0ELb1}; shift
+pat=${1:-megakernelILi0ELb0ELb0ELb1ELb0ELb1ELb1}; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize "$@" -S --cuda-device-only -o /tmp/pt_isa.s $root/cudapathtracer_amd/csrc/pt_mk_lds.hip 2>/dev/null
 awk "/^_ZN2pt[0-9]*${pat}[A-Za-z0-9_]*:/,/s_endpgm/" /tmp/pt_isa.s > /tmp/pt_isa_fn.s
