@@ -509,9 +509,12 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     // ... and only with enough tiles to fill its 6 waves per SIMD: with fewer (a 1/8 shard of a 1080p frame is 4050
     // tiles for 6144 slots) the extra slots stay empty and the 4-wave kernel's faster waves win (measured: 1/8 shard
     // 176 vs 185 ms, 1/4 shard equal, 1/2 shard 602 vs 518 ms on the 263 k-triangle scene).
-    const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * kWavesHbm * 5);
+    // ... of which the SIMPLE instantiation (diffuse-only scenes; timed launches with the resumable traversal) runs at 8 waves per SIMD
+    const bool simpleHbm = !onchip && !deferred && s->wavesHbmOk && s->simpleOk && s->simpleWanted && s->refill && !s->cull && !s->armless && !count;
+    const int wavesHbm = simpleHbm ? kWavesHbmSimple : kWavesHbm;
+    const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * wavesHbm * 5);
     const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
-    const int wgWaves = hbm ? kWgWavesHbm : 4;
+    const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : 4;
     int blocks = megakernel_blocks(t.count, wgWaves);
     if (spillEntries > 0)
         if (int r = s->spill.ensure((size_t)blocks * wgWaves * spillEntries * 64 * sizeof(int32_t))) return r;
@@ -528,7 +531,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cacheAttrs = P.cacheMats = P.cacheLights = 0;
     if (onchip && kAttrCacheBytes > 0) { P.cacheAttrs = s->nTrisPacked; P.cacheMats = s->nMats; P.cacheLights = s->nLightsPacked; }   // the bounce's records in LDS as well
     P.wgWaves = wgWaves;
-    if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, kCacheBytesHbm / 64);     // its workgroups share a larger copy of the top of the tree
+    if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
@@ -537,12 +540,13 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.spec = s->spec;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
     P.flat = (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) ? 1 : 0;
-    P.simple = ((P.flat || (hbm && P.refill)) && s->simpleOk && s->simpleWanted) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
+    P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || (hbm && simpleHbm)) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
-    P.wavesPerSimd = hbm ? kWavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
+    P.wavesPerSimd = hbm ? wavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
+    P.hbm = hbm ? 1 : 0;
     P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
     P.lptPrio = s->lptPrio; P.sliceIters = s->sliceIters; P.schedMask = s->schedMask; P.sliceAlways = s->sliceAlways ? 1 : 0;
     if (s->persistent && !s->xcdBands) {

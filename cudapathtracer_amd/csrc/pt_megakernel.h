@@ -144,7 +144,8 @@ PT_DEV void megakernel_body(const KParams& P) {
     // ONCHIP kernels: the host guarantees that the bounce's records fit as well (pt_api.hip: `onchip`), so their address
     // space is a compile-time fact and every access below is a ds_read.
     constexpr bool ATTRLDS = ONCHIP && kAttrCacheBytes > 0;
-    const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMediumMax * 64) : 0;
+    constexpr int kMedBytes = SIMPLE ? 0 : kMediumMax * 64;                 // SIMPLE kernels have no medium stack (pt_path.h)
+    const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMedBytes) : 0;
     const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights);      // contains the only barrier
     if constexpr (ATTRLDS) {
         // The bounce reads its records through S; pointing S at the LDS copies makes those loads ds_reads (the address
@@ -193,8 +194,10 @@ PT_DEV void megakernel_body(const KParams& P) {
     st.lds = (lds_i32*)(pt_smem + cacheBytes) + wave * (STACKN * 64) + lane;
     st.spill = P.spill ? P.spill + ((size_t)(blockIdx.x * nW + wave) * S.stackSpill) * 64 + lane : nullptr;
     st.sp = 0;
-    LdsMedium ms;
-    ms.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + nW * STACKN * 256) + wave * (kMediumMax * 64) + lane;
+    LdsMedium msLds;
+    msLds.p = (LdsMedium::lds_u8*)(pt_smem + cacheBytes + nW * STACKN * 256) + wave * kMedBytes + lane;
+    NoMedium msNone;
+    auto& ms = [&]() -> auto& { if constexpr (SIMPLE) return msNone; else return msLds; }();      // SIMPLE: no LDS behind it (kMedBytes = 0)
 
     PathState ps;
     const bool shared = P.queue != nullptr && !COUNT && P.sliceIters > 0;       // tiles may change hands
@@ -226,10 +229,10 @@ PT_DEV void megakernel_body(const KParams& P) {
 #endif
     auto shadowSync = [&](V3 ro, V3 wi, float maxt) {
         PT_STAMP(2);
-        V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+        V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
 #ifdef PT_DIAG_DOUBLE_SHADOW        // cost measurement only (tools/phase_cost.sh): the shadow ray traced twice, same result
         {
-            const V3 t2_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+            const V3 t2_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
             t_ = v3(fminf_(t_.x, t2_.x), fminf_(t_.y, t2_.y), fminf_(t_.z, t2_.z));
         }
 #endif
@@ -307,12 +310,12 @@ PT_DEV void megakernel_body(const KParams& P) {
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
 #if PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
-            if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
-            else trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+            else trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 1
-            trace_resume_spec<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+            trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
 #else
-            trace_resume<COUNT, STACKN, ONCHIP>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #endif
             PT_STAMP(1);
             continue;
@@ -418,6 +421,11 @@ megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
 megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE>(P); }
+
+// The SIMPLE production kernel for scenes in HBM: 8 waves per SIMD, 16-wave workgroups (pt_params.h).
+template <int INTEG>
+__global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
+megakernel_hbm_simple(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true>(P); }
 
 
 }  // namespace pt

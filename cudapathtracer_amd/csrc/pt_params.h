@@ -47,6 +47,13 @@ constexpr int kWgWavesHbm = (PT_WAVES_HBM > 0 && (kWavesHbm * 4) % PT_WG_WAVES_H
 constexpr int kCacheBytesHbm = kWgWavesHbm == 4 ? kCacheBytes
                                                 : ((160 * 1024) / ((kWavesHbm * 4) / kWgWavesHbm) - kWgWavesHbm * (kStackLdsHbm * 256 + kMediumMax * 64)) / 64 * 64;
 
+// The SIMPLE instantiation of the kernel for scenes in HBM (pt_path.h: diffuse-only scenes) is a third of the generic
+// kernel's code and holds less state: it runs best at 8 waves per SIMD (64 VGPRs) in workgroups of 16 waves — one LDS copy
+// of the top of the tree per 16 waves, and no medium stacks, so the copy is 48 KB (768 PNodes). The generic kernel is 13 %
+// SLOWER at 8 (spills) and stays at PT_WAVES_HBM (profiles/r02_ab_waves_simple.log).
+constexpr int kWavesHbmSimple = 8, kWgWavesHbmSimple = 16;
+constexpr int kCacheBytesHbmSimple = ((160 * 1024) / 2 - kWgWavesHbmSimple * (kStackLdsHbm * 256)) / 64 * 64;
+
 struct KParams {
     DeviceScene S;
     CamK cam;
@@ -63,7 +70,8 @@ struct KParams {
     int refillKeep;                // the wave leaves the traversal when no more than busy * refillKeep / 16 lanes are still tracing
     int spec;                      // REFILL kernels: 0 trace_resume, 1 speculative descent for closest-hit rays (pt_trace.h: trace_resume_spec), 2 also for shadow rays
     int wgWaves;                   // waves per workgroup of this launch (4, or kWgWavesHbm for megakernel_hbm)
-    int wavesPerSimd;              // which kernel: PT_MIN_WAVES (megakernel) or kWavesHbm (megakernel_hbm)
+    int wavesPerSimd;              // PT_MIN_WAVES (megakernel), kWavesHbm (megakernel_hbm) or kWavesHbmSimple (its SIMPLE instantiation)
+    int hbm;                       // 1: a megakernel_hbm launch (8-entry LDS stacks, the spill area laid out for them)
     int onchip;                    // 1: every PNode / PTri is in the LDS cache and the stack fits LDS -> ONCHIP kernels
     int xcdBands;                  // 1: workgroups of one XCD take a contiguous run of tiles (one L2 per XCD, MI355X_MICROARCH.md)
     uint32_t* rng;                 // [tile][6][64]
@@ -146,8 +154,8 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
 inline int megakernel_blocks(int tileCount, int wgWaves = 4) { return (tileCount + wgWaves - 1) / wgWaves; }
 inline size_t attr_cache_bytes(int nAttrs, int nMats, int nLights) { return (size_t)nAttrs * 80 + (size_t)nMats * 96 + (size_t)nLights * 64; }
-inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4, size_t attrBytes = 0) {
-    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (size_t)kMediumMax * 64) + attrBytes;
+inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4, size_t attrBytes = 0, bool mediumStacks = true) {
+    return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (mediumStacks ? (size_t)kMediumMax * 64 : 0)) + attrBytes;
 }
 
 }  // namespace pt

@@ -72,6 +72,10 @@ struct LdsMedium {
     PT_DEV int get(int i) const { return p[i * 64]; }
     PT_DEV void set(int i, int v) { p[i * 64] = (uint8_t)v; }
 };
+struct NoMedium {                    // SIMPLE kernels: the stack would only ever hold air (material 0)
+    PT_DEV int get(int) const { return 0; }
+    PT_DEV void set(int, int) {}
+};
 struct RegMedium {
     uint32_t w0, w1, w2, w3;
     PT_DEV int get(int i) const {

@@ -305,7 +305,8 @@ PT_DEV float schlick_fresnel(float cosTheta, float etaI, float etaT) {    // ref
 
 // BVHShadowRay (integratorUtilities.cuh:188-288): any hit below max_t kills the ray unless the
 // triangle's material is MAT_LEAF, which attenuates and continues (cut-off 0.01).
-template <bool COUNT, int N, bool ONCHIP, bool CULL>
+// NOLEAF (SIMPLE scenes, pt_path.h): no triangle carries a MAT_LEAF material, so every hit below max_t ends the ray.
+template <bool COUNT, int N, bool ONCHIP, bool CULL, bool NOLEAF = false>
 PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c) {
     V3 inv = inv3(d);
     V3 thr = v3(1.0f);
@@ -327,7 +328,7 @@ PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < max_t)) {
                 uint32_t flags = f2u(q.e.w);
-                if (!(flags & 1u)) return v3(0.0f);
+                if (NOLEAF || !(flags & 1u)) return v3(0.0f);
                 // MAT_LEAF (integratorUtilities.cuh:218-239)
                 const PMat& m = S.mats[f2i(q.e.z)];
                 const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -347,7 +348,7 @@ PT_DEV V3 trace_shadow_plain(const DeviceScene& S, const SceneCache& C, V3 o, V3
 }
 
 // ... and with the loop exits of LoopExit.
-template <bool COUNT, int N, bool ONCHIP, bool CULL>
+template <bool COUNT, int N, bool ONCHIP, bool CULL, bool NOLEAF = false>
 PT_DEV V3 trace_shadow_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k) {
     typedef LoopExit<ONCHIP> X;
     V3 inv = inv3(d);
@@ -379,7 +380,7 @@ PT_DEV V3 trace_shadow_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (ok && (t < max_t)) {
                 uint32_t flags = f2u(q.e.w);
-                if (!(flags & 1u)) { if (COUNT) c.pops++; return v3(0.0f); }
+                if (NOLEAF || !(flags & 1u)) { if (COUNT) c.pops++; return v3(0.0f); }
                 // MAT_LEAF (integratorUtilities.cuh:218-239)
                 const PMat& m = S.mats[f2i(q.e.z)];
                 const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -402,10 +403,10 @@ PT_DEV V3 trace_shadow_exits(const DeviceScene& S, const SceneCache& C, V3 o, V3
     return thr;
 }
 
-template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
+template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false, bool NOLEAF = false>
 PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, float max_t, Stack<N>& st, Ctr& c, Keep k = Keep{0, 0}) {
-    if (LoopExit<ONCHIP>::node || LoopExit<ONCHIP>::tri) return trace_shadow_exits<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, c, k);
-    return trace_shadow_plain<COUNT, N, ONCHIP, CULL>(S, C, o, d, max_t, st, c);
+    if (LoopExit<ONCHIP>::node || LoopExit<ONCHIP>::tri) return trace_shadow_exits<COUNT, N, ONCHIP, CULL, NOLEAF>(S, C, o, d, max_t, st, c, k);
+    return trace_shadow_plain<COUNT, N, ONCHIP, CULL, NOLEAF>(S, C, o, d, max_t, st, c);
 }
 
 
@@ -757,7 +758,7 @@ PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasS
 }
 
 // (eo, ed): the lane's extension ray, needed when its shadow ray ends inside this call.
-template <bool COUNT, int N, bool ONCHIP>
+template <bool COUNT, int N, bool ONCHIP, bool NOLEAF = false>
 PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
                          V3& thr, Hit& h, Ctr& c, Keep k = Keep{0, 0}) {
     typedef LoopExit<ONCHIP> X;
@@ -805,7 +806,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
             if (isShadow) {
                 if (ok && (t < max_t)) {
                     uint32_t flags = f2u(q.e.w);
-                    if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                    if (NOLEAF || !(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
                     // MAT_LEAF (integratorUtilities.cuh:218-239)
                     const PMat& m = S.mats[f2i(q.e.z)];
                     const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -851,7 +852,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
 // strictly in the reference's order (the counting kernels need that: their node counters are compared with the oracle's).
 constexpr int32_t kRefHold = (int32_t)0x80000001;      // "the next ref is popped after the pending leaf" (no speculation for this ray)
 
-template <bool COUNT, int N, bool ONCHIP>
+template <bool COUNT, int N, bool ONCHIP, bool NOLEAF = false>
 PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
                               V3& thr, Hit& h, Ctr& c, Keep k, bool specShadow) {
     typedef LoopExit<ONCHIP> X;
@@ -896,7 +897,7 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
                 if (isShadow) {
                     if (ok && (t < max_t)) {
                         uint32_t flags = f2u(q.e.w);
-                        if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                        if (NOLEAF || !(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
                         // MAT_LEAF (integratorUtilities.cuh:218-239)
                         const PMat& m = S.mats[f2i(q.e.z)];
                         const PAttr& at = S.attrs[idx & 0x7fffffffu];
