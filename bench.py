@@ -85,7 +85,9 @@ def kernel_name(flags, variant):
     if variant != "megakernel":
         return "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)"
     if flags["hbm_kernel"]:
-        return "pt::megakernel_hbm<0, false, %s, %s, %s>" % (_tf(flags["culling"]), _tf(flags["refill"]), _tf(flags.get("simple", False)))
+        if flags.get("simple"):
+            return "pt::megakernel_hbm_simple<0>"
+        return "pt::megakernel_hbm<0, false, %s, %s, false>" % (_tf(flags["culling"]), _tf(flags["refill"]))
     if flags.get("simple"):
         return "pt::megakernel<0, false, false, true, false, true, true>"
     return "pt::megakernel<0, false, false, %s, %s, %s, false>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))

@@ -14,7 +14,8 @@ run_pmc() {  # workload spp name
   ms=$(python - <<PY
 import csv,glob
 rows=[r for f in glob.glob("$out/pmc_$3/pass2/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
-t=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6 for r in rows if "megakernel" in r["Kernel_Name"] and "<0, false" in r["Kernel_Name"]]
+import re
+t=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6 for r in rows if "megakernel" in r["Kernel_Name"] and not re.search(r"megakernel(_hbm)?<\d, ?true", r["Kernel_Name"])]
 print("%.3f" % t[-1])
 PY
 )

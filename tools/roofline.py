@@ -26,6 +26,7 @@ by LDS (Cornell) or L1/L2 — that ratio is not a roofline fraction and is no lo
 """
 import csv
 import glob
+import re
 import json
 import os
 import sys
@@ -107,7 +108,7 @@ def collect(outdir, workload, spp, kernel_ms=None):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 name = r["Kernel_Name"].split("(")[0].strip()
-                if "megakernel" not in name or "<0, false" not in name.replace("<0,false", "<0, false"):
+                if "megakernel" not in name or re.search(r"megakernel(_hbm)?<\d, ?true", name):      # counting instantiations: COUNT = true
                     continue
                 d = per.setdefault(name, {})
                 d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
