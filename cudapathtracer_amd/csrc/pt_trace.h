@@ -849,7 +849,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
 // trips saved are paid for by the ballot and the postponement logic in every trip, and this kernel is not bound by the
 // lanes of its node loop alone. Not the default: build with -DPT_SPEC=1 to reproduce.
 // A shadow ray that the postponed leaf will occlude descends a few nodes in vain; `specShadow` = false keeps shadow rays
-// strictly in the reference's order (the counting kernels need that: their node counters are compared with the oracle's).
+// strictly in the reference's order (the counting kernels need that: their node counters are part of the parity contract).
 constexpr int32_t kRefHold = (int32_t)0x80000001;      // "the next ref is popped after the pending leaf" (no speculation for this ray)
 
 template <bool COUNT, int N, bool ONCHIP, bool NOLEAF = false>
