@@ -73,7 +73,7 @@ struct pt_scene {
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
-    bool flatOk = false, flatWanted = true;   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
+    bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 for scenes of at most 64 nodes / triangles, 2 also the 128-bit form (65..128: measured slower, A/B only)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0;
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
@@ -94,10 +94,17 @@ static int queue_error(pt_scene* s);
 
 // LDS-resident instantiation: every PNode and PTri in the scene cache, the tree no deeper than the LDS stack, and the
 // records the bounce reads (PAttr, PMat, PLight) within their own LDS budget.
-static bool scene_onchip(const pt_scene* s) {
-    return s->onchipOk && s->cacheNodes >= s->nInternal && s->cacheTris >= s->nTrisPacked && s->nTrisPacked > 0 && s->ds.stackSpill == 0 &&
-           (kAttrCacheBytes == 0 || attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked) <= (size_t)kAttrCacheBytes);
+// Its workgroups hold ONE copy of the scene each, and a CU has 160 KB of LDS for its 16 waves: workgroups of 4, 8 or 16
+// waves get 1, 2 or 4 times the budgets kCacheBytes (PNodes + PTris) and kAttrCacheBytes. Returns the smallest workgroup
+// size (in waves) that holds the scene, 0 if none does.
+static int scene_onchip_wg(const pt_scene* s) {
+    if (!s->onchipOk || s->nTrisPacked <= 0 || s->ds.stackSpill != 0) return 0;
+    const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked);
+    for (int wg = 4; wg <= 16; wg *= 2)
+        if (geom <= (size_t)kCacheBytes * (wg / 4) && (kAttrCacheBytes == 0 || rec <= (size_t)kAttrCacheBytes * (wg / 4))) return wg;
+    return 0;
 }
+static bool scene_onchip(const pt_scene* s) { return scene_onchip_wg(s) > 0; }
 
 extern "C" {
 
@@ -334,11 +341,11 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
     s->nTrisPacked = nT;
     if ((size_t)nInternal * 64 + (size_t)nT * 48 <= (size_t)kCacheBytes) { s->cacheNodes = nInternal; s->cacheTris = nT; }
     else { s->cacheNodes = std::min(nInternal, kCacheBytes / 64); s->cacheTris = 0; }
-    // FLAT kernels (pt_trace.h): one forward pass over the internal nodes with 64-bit masks — needs at most 64 of each,
-    // every child numbered after its parent (the breadth-first numbering gives that; checked on the packed records) and
-    // the triangle count of every leaf child, which goes into the spare words of its PNode.
+    // FLAT kernels (pt_trace.h): one forward pass over the internal nodes with 64- or 128-bit masks — needs at most 128 of
+    // each, every child numbered after its parent (the breadth-first numbering gives that; checked on the packed records)
+    // and the triangle count of every leaf child, which goes into the spare words of its PNode.
     s->flatOk = false;
-    if (nInternal <= 64 && nT >= 1 && nT <= 64 && s->cacheNodes == nInternal && s->cacheTris == nT) {
+    if (nInternal <= 128 && nT >= 1 && nT <= 128 && scene_onchip_wg(s) > 0) {
         std::vector<PNode> pn((size_t)std::max(nInternal, 1));
         std::vector<PTri> pt((size_t)nT);
         if (nInternal > 0) HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nInternal * sizeof(PNode), hipMemcpyDeviceToHost));
@@ -504,8 +511,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (int r = s->rng.ensure((size_t)t.count * 384 * sizeof(uint32_t))) return r;
     // Which kernel (pt_kernels.hip): the LDS-resident instantiation, or — for a scene in HBM — the 6-waves-per-SIMD
     // one with its shorter LDS stack (so the spill area is laid out for THAT stack length).
-    const bool onchip = scene_onchip(s);
     const bool deferred = s->deferShadow && !s->armless;
+    const bool onchip = scene_onchip(s) && !deferred;       // (the DEFER A/B instantiation exists for the general 4-wave kernel only)
     // ... and only with enough tiles to fill its 6 waves per SIMD: with fewer (a 1/8 shard of a 1080p frame is 4050
     // tiles for 6144 slots) the extra slots stay empty and the 4-wave kernel's faster waves win (measured: 1/8 shard
     // 176 vs 185 ms, 1/4 shard equal, 1/2 shard 602 vs 518 ms on the 263 k-triangle scene).
@@ -514,7 +521,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     const int wavesHbm = simpleHbm ? kWavesHbmSimple : kWavesHbm;
     const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * wavesHbm * 5);
     const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
-    const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : 4;
+    const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
     if (spillEntries > 0)
         if (int r = s->spill.ensure((size_t)blocks * wgWaves * spillEntries * 64 * sizeof(int32_t))) return r;
@@ -528,6 +535,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.w = w; P.h = h; P.spp = spp; P.maxDepth = maxDepth; P.useMIS = useMIS;
     P.tileFirst = t.first; P.tileStride = t.stride; P.tileCount = t.count; P.tilesX = t.tilesX;
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
+    if (onchip) { P.cacheNodes = s->nInternal; P.cacheTris = s->nTrisPacked; }      // the whole scene, in workgroups large enough to hold it
     P.cacheAttrs = P.cacheMats = P.cacheLights = 0;
     if (onchip && kAttrCacheBytes > 0) { P.cacheAttrs = s->nTrisPacked; P.cacheMats = s->nMats; P.cacheLights = s->nLightsPacked; }   // the bounce's records in LDS as well
     P.wgWaves = wgWaves;
@@ -539,7 +547,11 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.refillKeep = s->refillKeep;
     P.spec = s->spec;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
-    P.flat = (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) ? 1 : 0;
+    P.flat = 0;                                             // 1: FLAT with 64-bit masks, 2: with 128-bit masks
+    if (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) {
+        if (s->nInternal <= 64 && s->nTrisPacked <= 64) P.flat = 1;
+        else if (s->flatWanted == 2) P.flat = 2;           // 65..128: loses to the stack walk from ~80 triangles on (profiles/r02_flat_crossover.jsonl)
+    }
     P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || (hbm && simpleHbm)) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
@@ -726,7 +738,7 @@ int pt_set_culling(pt_scene* s, int on) {
 namespace {
 struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
-    {"flat", 0, 1}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
+    {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
     {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1},
 };
@@ -743,7 +755,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
     if (k < 0) return fail(-1, "pt_set_option: unknown option '%s'", name ? name : "(null)");
     if (v < kOptions[k].lo || v > kOptions[k].hi) return fail(-1, "pt_set_option: %s = %d is outside [%d, %d]", name, v, kOptions[k].lo, kOptions[k].hi);
     switch (k) {
-        case 0: s->flatWanted = v != 0; break;
+        case 0: s->flatWanted = v; break;
         case 1: s->onchipOk = v != 0; break;
         case 2: s->wavesHbmOk = v != 0 && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && v == 2; break;
         case 3: s->refill = v; break;

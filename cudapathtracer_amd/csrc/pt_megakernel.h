@@ -137,7 +137,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1>
 PT_DEV void megakernel_body(const KParams& P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
@@ -338,9 +338,9 @@ PT_DEV void megakernel_body(const KParams& P) {
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
         else if constexpr (FLAT) {
-            trace_closest_flat<STACKN>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes);
+            trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes);
 #ifdef PT_DIAG_DOUBLE_CLOSEST       // cost measurement only: the closest-hit traversal run twice, same result
-            { Hit h2; trace_closest_flat<STACKN>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h2, c, P.cacheNodes); if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); }
+            { Hit h2; trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h2, c, P.cacheNodes); if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); }
 #endif
         }
         else if (hasExt) trace_closest<COUNT, STACKN, ONCHIP, CULL>(S, SC, ps.o, ps.d, 999999.0f, st, h, c, Keep{P.nodeKeep, P.triKeep});
@@ -411,12 +411,14 @@ PT_DEV void megakernel_body(const KParams& P) {
 // 4 waves per SIMD with 128 VGPRs; a scene in HBM is latency-bound (waves wait on memory 66 % of their
 // cycles at 4 waves) and gains 18 % from 6 waves per SIMD at 80 VGPRs and an 8-entry LDS stack, spills
 // included (5: +10 %, 7-8: no better). Both run the same body.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false, bool SIMPLE = false>
-__global__ void __launch_bounds__(256)
+// LDS-resident scenes run in workgroups of 4, 8 or 16 waves (the host picks the smallest whose LDS share holds the scene:
+// one copy of the scene per workgroup), hence the launch bound of 1024 for ONCHIP kernels; 4 waves per SIMD either way.
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1>
+__global__ void __launch_bounds__(ONCHIP ? 1024 : 256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
 #endif
-megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT, SIMPLE>(P); }
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT, SIMPLE, FLATW>(P); }
 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))

@@ -7,15 +7,20 @@
 namespace pt {
 
 hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, dim3 grid, dim3 block, unsigned lds, hipStream_t stream) {
-#define PT_LAUNCH(I, C, RF, FL) hipLaunchKernelGGL((megakernel<I, C, false, true, RF, FL>), grid, block, lds, stream, P)
+    // workgroups of 8 or 16 waves may need more than the default 64 KB of dynamic LDS: raised per kernel below
+#define PT_LDS_OK(K) do { if (lds > 65536u) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e_ != hipSuccess) return e_; } } while (0)
+#define PT_LAUNCH(I, C, RF, FL) do { PT_LDS_OK((megakernel<I, C, false, true, RF, FL>)); hipLaunchKernelGGL((megakernel<I, C, false, true, RF, FL>), grid, block, lds, stream, P); } while (0)
 #define PT_PICK(I) do { if (P.refill) { if (count) PT_LAUNCH(I, true, true, false); else PT_LAUNCH(I, false, true, false); } \
-                        else if (P.flat && !count && P.simple) hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true>), grid, block, lds, stream, P); \
+                        else if (P.flat == 2 && !count && P.simple) { PT_LDS_OK((megakernel<I, false, false, true, false, true, true, 2>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true, 2>), grid, block, lds, stream, P); } \
+                        else if (P.flat == 2 && !count) { PT_LDS_OK((megakernel<I, false, false, true, false, true, false, 2>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, false, 2>), grid, block, lds, stream, P); } \
+                        else if (P.flat && !count && P.simple) { PT_LDS_OK((megakernel<I, false, false, true, false, true, true>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true>), grid, block, lds, stream, P); } \
                         else if (P.flat && !count) PT_LAUNCH(I, false, false, true); \
                         else if (count) PT_LAUNCH(I, true, false, false); \
                         else PT_LAUNCH(I, false, false, false); } while (0)
     if (integrator == 2) PT_PICK(2); else PT_PICK(0);
 #undef PT_PICK
 #undef PT_LAUNCH
+#undef PT_LDS_OK
     return hipGetLastError();
 }
 

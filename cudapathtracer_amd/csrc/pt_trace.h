@@ -410,7 +410,7 @@ PT_DEV V3 trace_shadow(const DeviceScene& S, const SceneCache& C, V3 o, V3 d, fl
 }
 
 
-// ---- FLAT closest hit: tiny LDS-resident scenes (at most 64 internal nodes and 64 packed triangles) ----
+// ---- FLAT closest hit: tiny LDS-resident scenes (at most 64 W internal nodes and 64 W packed triangles, W = 1 or 2) ----
 // Without culling the set of leaves a ray visits does not depend on what it hits: a leaf is visited iff slab() passes
 // for every box on the way down. The stack walk of a Cornell-class scene spends its time diverged (a trip through
 // the node loop carries 24 of 64 lanes, through the triangle loop 16, tools/lane_util.py). Here the wave works as one:
@@ -440,22 +440,62 @@ PT_DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Bit sets of W x 64 bits for the FLAT traversal (W = 1: at most 64 internal nodes / triangles; W = 2: 128).
+template <int W> struct BitSet {
+    uint64_t w[W];
+    PT_DEV static BitSet zero() { BitSet m; for (int j = 0; j < W; j++) m.w[j] = 0ull; return m; }
+    PT_DEV static BitSet range(int first, int count) {             // bits [first, first + count), count >= 0
+        BitSet m;
+        for (int j = 0; j < W; j++) {
+            const int lo = first - 64 * j, hi = lo + count;         // the range in this word's coordinates
+            const int a = lo < 0 ? 0 : lo, b = hi > 64 ? 64 : hi;
+            m.w[j] = (b > a) ? ((~0ull >> (64 - (b - a))) << a) : 0ull;
+        }
+        return m;
+    }
+    PT_DEV bool test(int i) const { uint64_t x = w[0]; for (int j = 1; j < W; j++) x = (i >> 6) == j ? w[j] : x; return ((x >> (i & 63)) & 1ull) != 0ull; }
+    PT_DEV void or_if(bool c, const BitSet& o) { for (int j = 0; j < W; j++) w[j] |= c ? o.w[j] : 0ull; }
+    PT_DEV BitSet operator&(const BitSet& o) const { BitSet m; for (int j = 0; j < W; j++) m.w[j] = w[j] & o.w[j]; return m; }
+    PT_DEV bool any() const { uint64_t x = 0ull; for (int j = 0; j < W; j++) x |= w[j]; return x != 0ull; }
+    PT_DEV int count() const { int n = 0; for (int j = 0; j < W; j++) n += (int)__builtin_popcountll(w[j]); return n; }
+    PT_DEV int first() const {                                     // lowest set bit (the set is not empty)
+        int p = 0; bool found = false;
+        for (int j = 0; j < W; j++) if (!found && w[j]) { p = 64 * j + (int)__builtin_ctzll(w[j]); found = true; }
+        return p;
+    }
+    PT_DEV void clear_first() {                                    // remove the lowest set bit
+        bool done = false;
+        for (int j = 0; j < W; j++) if (!done && w[j]) { w[j] &= w[j] - 1ull; done = true; }
+    }
+    PT_DEV void keep_from_kth(int k) {                             // drop the k lowest set bits
+        for (int j = 0; j < W; j++) {
+            const int c = (int)__builtin_popcountll(w[j]);
+            if (k >= c) { k -= c; w[j] = 0ull; }
+            else { if (k > 0) w[j] &= ~((1ull << select64(w[j], k)) - 1ull); k = 0; }
+        }
+    }
+};
+
 // All 64 lanes call this together; `active` says who has a ray. PNode.pad0 / pad1 hold the number of triangles
 // below the left / right child (patched in by the host for scenes that qualify, pt_api.hip).
-template <int N>
+template <int N, int W = 1>
 PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool active, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nInternal) {
-    static_assert(N >= 13, "the scratch layout needs 13 x 64 words of the wave's stack");
+    static_assert(N >= 11 + 2 * W, "the scratch layout needs (11 + 2 W) x 64 words of the wave's stack");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    typedef BitSet<W> Set;
+    constexpr int kTm = 6, kPre = 6 + 2 * W, kKeys = 7 + 2 * W;     // scratch fields: o 0-2, d 3-5, tm, exclusive prefix, 2 x u64 keys
+    constexpr int kMaxI = 64 * W - 1;
     const int lane = (int)(threadIdx.x & 63u);
-    lds_i32* W = st.lds - lane;                                  // the wave's 16 x 64 words; field f of lane l at W[f * 64 + l]
+    lds_i32* Wd = st.lds - lane;                                 // the wave's stack words; field f of lane l at Wd[f * 64 + l]
     const V3 inv = inv3(d);
     // 1. lockstep node walk
-    uint64_t tm = 0ull;
-    if (S.rootRef < 0) tm = active ? ~0ull >> (64 - S.nTris) : 0ull;      // the root is the only leaf
+    Set tm = Set::zero();
+    if (S.rootRef < 0) { if (active) tm = Set::range(0, S.nTris); }      // the root is the only leaf
     else {
-        uint64_t vis = active ? 1ull << (uint32_t)S.rootRef : 0ull;
+        Set vis = Set::zero();
+        if (active) vis = Set::range(S.rootRef, 1);
         for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
-            const bool v = ((vis >> i) & 1ull) != 0ull;
+            const bool v = vis.test(i);
             if (__builtin_amdgcn_ballot_w64(v) == 0ull) continue;
             const NodeData n = load_node<true>(S, C, i);          // uniform address: an LDS broadcast
             float tL, tR;
@@ -463,15 +503,13 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
             const bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR) && v;
             const int32_t left = __builtin_amdgcn_readfirstlane(f2i(n.d.x)), right = __builtin_amdgcn_readfirstlane(f2i(n.d.y));
             const int32_t cntL = __builtin_amdgcn_readfirstlane(f2i(n.d.z)), cntR = __builtin_amdgcn_readfirstlane(f2i(n.d.w));
-            const uint64_t bL = left >= 0 ? 1ull << (uint32_t)left : (~0ull >> (64 - cntL)) << (uint32_t)(~left);
-            const uint64_t bR = right >= 0 ? 1ull << (uint32_t)right : (~0ull >> (64 - cntR)) << (uint32_t)(~right);
-            if (left >= 0) vis |= hL ? bL : 0ull; else tm |= hL ? bL : 0ull;
-            if (right >= 0) vis |= hR ? bR : 0ull; else tm |= hR ? bR : 0ull;
+            if (left >= 0) vis.or_if(hL, Set::range(left, 1)); else tm.or_if(hL, Set::range(~left, cntL));
+            if (right >= 0) vis.or_if(hR, Set::range(right, 1)); else tm.or_if(hR, Set::range(~right, cntR));
         }
     }
     // 2. deal the tests out: lane j takes tests [j * per, (j + 1) * per) of the wave's sequence (rays in lane order,
     //    triangles in index order) — consecutive tests mostly belong to one ray, which the lane keeps in registers
-    const int n = (int)__builtin_popcountll(tm);
+    const int n = tm.count();
     int pre = n;                                                  // inclusive prefix sum: DPP inside rows of 16, then the row totals
     pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, true);      // row_shr:1
     pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, true);      // row_shr:2
@@ -481,44 +519,49 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     pre += (lane >= 16 ? r0 : 0) + (lane >= 32 ? r1 : 0) + (lane >= 48 ? r2 : 0);
     const int total = __builtin_amdgcn_readlane(pre, 63);         // wave-uniform
     pre -= n;                                                    // exclusive prefix
-    W[0 * 64 + lane] = __builtin_bit_cast(int32_t, o.x); W[1 * 64 + lane] = __builtin_bit_cast(int32_t, o.y); W[2 * 64 + lane] = __builtin_bit_cast(int32_t, o.z);
-    W[3 * 64 + lane] = __builtin_bit_cast(int32_t, d.x); W[4 * 64 + lane] = __builtin_bit_cast(int32_t, d.y); W[5 * 64 + lane] = __builtin_bit_cast(int32_t, d.z);
-    W[6 * 64 + lane] = (int32_t)(uint32_t)tm; W[7 * 64 + lane] = (int32_t)(uint32_t)(tm >> 32);
-    W[8 * 64 + lane] = pre;
-    lds_u64* kLo = (lds_u64*)(W + 9 * 64);                        // min over (t bits, triangle index)
-    lds_u64* kHi = (lds_u64*)(W + 11 * 64);                       // min over (t bits, 63 - triangle index)
+    Wd[0 * 64 + lane] = __builtin_bit_cast(int32_t, o.x); Wd[1 * 64 + lane] = __builtin_bit_cast(int32_t, o.y); Wd[2 * 64 + lane] = __builtin_bit_cast(int32_t, o.z);
+    Wd[3 * 64 + lane] = __builtin_bit_cast(int32_t, d.x); Wd[4 * 64 + lane] = __builtin_bit_cast(int32_t, d.y); Wd[5 * 64 + lane] = __builtin_bit_cast(int32_t, d.z);
+    for (int j = 0; j < W; j++) { Wd[(kTm + 2 * j) * 64 + lane] = (int32_t)(uint32_t)tm.w[j]; Wd[(kTm + 2 * j + 1) * 64 + lane] = (int32_t)(uint32_t)(tm.w[j] >> 32); }
+    Wd[kPre * 64 + lane] = pre;
+    lds_u64* kLo = (lds_u64*)(Wd + kKeys * 64);                   // min over (t bits, triangle index)
+    lds_u64* kHi = (lds_u64*)(Wd + (kKeys + 2) * 64);             // min over (t bits, kMaxI - triangle index)
     kLo[lane] = ~0ull; kHi[lane] = ~0ull;
     wave_lds_sync();
+    auto load_set = [&](int l) {
+        Set m;
+        for (int j = 0; j < W; j++) m.w[j] = (uint64_t)(uint32_t)Wd[(kTm + 2 * j) * 64 + l] | ((uint64_t)(uint32_t)Wd[(kTm + 2 * j + 1) * 64 + l] << 32);
+        return m;
+    };
     const int per = (total + 63) >> 6;
     int p = lane * per;
     const int pEnd = (p + per < total) ? p + per : total;
     int l = 0;
-    uint64_t rem = 0ull;
+    Set rem = Set::zero();
     V3 ro = v3(0.0f), rd = v3(0.0f);
     if (p < pEnd) {
-        for (int s = 32; s; s >>= 1) { const int cand = l + s; if (W[8 * 64 + cand] <= p) l = cand; }      // owner of test p: the last lane whose exclusive prefix is <= p
-        const uint64_t tml = (uint64_t)(uint32_t)W[6 * 64 + l] | ((uint64_t)(uint32_t)W[7 * 64 + l] << 32);
-        rem = tml & ~((1ull << select64(tml, p - W[8 * 64 + l])) - 1ull);                                    // its triangles from the (p - prefix)-th on
-        ro = v3(__builtin_bit_cast(float, W[0 * 64 + l]), __builtin_bit_cast(float, W[1 * 64 + l]), __builtin_bit_cast(float, W[2 * 64 + l]));
-        rd = v3(__builtin_bit_cast(float, W[3 * 64 + l]), __builtin_bit_cast(float, W[4 * 64 + l]), __builtin_bit_cast(float, W[5 * 64 + l]));
+        for (int s = 32; s; s >>= 1) { const int cand = l + s; if (Wd[kPre * 64 + cand] <= p) l = cand; }      // owner of test p: the last lane whose exclusive prefix is <= p
+        rem = load_set(l);
+        rem.keep_from_kth(p - Wd[kPre * 64 + l]);                                                             // its triangles from the (p - prefix)-th on
+        ro = v3(__builtin_bit_cast(float, Wd[0 * 64 + l]), __builtin_bit_cast(float, Wd[1 * 64 + l]), __builtin_bit_cast(float, Wd[2 * 64 + l]));
+        rd = v3(__builtin_bit_cast(float, Wd[3 * 64 + l]), __builtin_bit_cast(float, Wd[4 * 64 + l]), __builtin_bit_cast(float, Wd[5 * 64 + l]));
     }
     for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
         if (p < pEnd) {
-            while (rem == 0ull) {                                 // next ray that has tests (there is one: p < total)
+            while (!rem.any()) {                                  // next ray that has tests (there is one: p < total)
                 l++;
-                rem = (uint64_t)(uint32_t)W[6 * 64 + l] | ((uint64_t)(uint32_t)W[7 * 64 + l] << 32);
-                ro = v3(__builtin_bit_cast(float, W[0 * 64 + l]), __builtin_bit_cast(float, W[1 * 64 + l]), __builtin_bit_cast(float, W[2 * 64 + l]));
-                rd = v3(__builtin_bit_cast(float, W[3 * 64 + l]), __builtin_bit_cast(float, W[4 * 64 + l]), __builtin_bit_cast(float, W[5 * 64 + l]));
+                rem = load_set(l);
+                ro = v3(__builtin_bit_cast(float, Wd[0 * 64 + l]), __builtin_bit_cast(float, Wd[1 * 64 + l]), __builtin_bit_cast(float, Wd[2 * 64 + l]));
+                rd = v3(__builtin_bit_cast(float, Wd[3 * 64 + l]), __builtin_bit_cast(float, Wd[4 * 64 + l]), __builtin_bit_cast(float, Wd[5 * 64 + l]));
             }
-            const int ti = __builtin_ctzll(rem);
-            rem &= rem - 1ull;
+            const int ti = rem.first();
+            rem.clear_first();
             const TriData q = load_tri<true>(S, C, ti);
             float t, u, v;
             const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), ro, rd, t, u, v);
             if (ok && (t < max_t)) {
                 const uint64_t tb = (uint64_t)f2u(t) << 32;           // t > 0: the bit pattern orders like the value
                 __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(63 - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(kMaxI - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             p++;
         }
@@ -533,25 +576,25 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
         hit.tri = -1;
         if (a != ~0ull) {
             int win = (int)(uint32_t)a;
-            const int last = 63 - (int)(uint32_t)b;
+            const int last = kMaxI - (int)(uint32_t)b;
             if (win != last) {
                 const uint32_t tmin = (uint32_t)(a >> 32);
-                uint64_t tied = 0ull;
-                for (uint64_t rest = tm; rest; rest &= rest - 1ull) {
-                    const int ti = __builtin_ctzll(rest);
+                Set tied = Set::zero();
+                for (Set rest = tm; rest.any(); rest.clear_first()) {
+                    const int ti = rest.first();
                     const TriData q = load_tri<true>(S, C, ti);
                     float t, u, v;
                     const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
-                    if (ok && (t < max_t) && f2u(t) == tmin) tied |= 1ull << ti;
+                    tied.or_if(ok && (t < max_t) && f2u(t) == tmin, Set::range(ti, 1));
                 }
                 int32_t ref = S.rootRef;
                 int lo = 0;                                        // first triangle of the current subtree (leaf order = left to right)
                 while (ref >= 0) {
                     const NodeData nd = load_node<true>(S, C, ref);
                     const int mid = lo + f2i(nd.d.z), hi = mid + f2i(nd.d.w);
-                    const uint64_t inL = tied & ((~0ull >> (64 - (mid - lo))) << lo), inR = tied & ((~0ull >> (64 - (hi - mid))) << mid);
-                    bool goLeft = inR == 0ull;
-                    if (inL != 0ull && inR != 0ull) {
+                    const Set inL = tied & Set::range(lo, mid - lo), inR = tied & Set::range(mid, hi - mid);
+                    bool goLeft = !inR.any();
+                    if (inL.any() && inR.any()) {
                         float tL, tR;
                         slab(nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, o, inv, tL);
                         slab(nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, o, inv, tR);
@@ -561,7 +604,7 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
                     if (!goLeft) lo = mid;
                     tied = goLeft ? inL : inR;
                 }
-                win = __builtin_ctzll(tied);                       // inside the leaf: the first in leaf order
+                win = tied.first();                                // inside the leaf: the first in leaf order
             }
             const TriData q = load_tri<true>(S, C, win);
             float t, u, v;

@@ -194,7 +194,8 @@ int pt_set_culling(pt_scene* scene, int on);
  * process renders cannot be steered from its environment. Only "culling" (= pt_set_culling) can reach the image; all
  * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
- *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes (default 1)
+ *   "flat" 0|1|2          FLAT closest-hit traversal: off / LDS-resident scenes of at most 64 nodes and triangles (default) /
+ *                         also its 128-bit form for 65..128 (measured slower than the stack walk from ~80 triangles on)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)

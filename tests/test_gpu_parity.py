@@ -744,3 +744,45 @@ def test_simple_bounce_specialisation(api, oracle, gpu_ready, scene_dir):
         col, _ = gs.render(hs.camera(), 40, 24, 6, 16, integrator=integ)
         assert gs.flags()["simple"]
         assert_bits_equal(col, ocol, "diffuse-only scene, depth 16, integrator %d" % integ)
+
+
+@pytest.mark.parametrize("integrator", [0, 2])
+def test_flat_128_and_larger_workgroups(api, oracle, gpu_ready, scene_dir, integrator):
+    """LDS-resident scenes beyond Cornell: 65-128 triangles run the FLAT traversal with 128-bit masks (incl. a doubled box:
+    every hit on it is a two-way tie; opt-in, "flat" = 2), and scenes whose records need more LDS than a 4-wave workgroup's share run in
+    workgroups of 8 or 16 waves that hold one copy of the scene — FLAT up to 128 triangles, the stack walk beyond.
+    Timed and counting kernels against the oracle, bit for bit."""
+    from cudapathtracer_amd import scenes
+    cases = [("x3", dict(extra_boxes=3), True),                                                    # 72 triangles, diffuse only (SIMPLE)
+             ("x5mix", dict(extra_boxes=5, tall_material=19, short_material=5, nested=True), True),      # 108: mirror, glass, nested water
+             ("x5twin", dict(extra_boxes=5, doubled=19), True),                                    # 108 with a doubled box: ties
+             ("x7", dict(extra_boxes=7, ceiling_light=True), True)]                                # 120 triangles
+    for name, kw, want_flat in cases:
+        cfg = scenes.cornell(os.path.join(scene_dir, "f128_" + name), 40, 24, 5, 7, name=name, **kw)["config"]
+        gs, hs, osc = _scene_pair(api, oracle, cfg, options={"flat": 2})          # the 128-bit form is opt-in (slower than the stack walk from ~80 triangles on)
+        i = hs.info
+        assert 64 < i["n_tris"] <= 128, i["n_tris"]
+        ocol, ocnt, _ = osc.render(integrator=integrator, counters=True, threads=8)
+        col, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
+        fl = gs.flags()
+        assert fl["onchip"] and fl["flat"] == want_flat, (name, fl)
+        assert_bits_equal(col, ocol, "%s: FLAT with 128-bit masks" % name)
+        col2, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator, counters=True)
+        assert np.array_equal(cnt, ocnt), name
+        assert_bits_equal(col2, ocol, "%s: counting kernel" % name)
+        gs0 = api.Scene(hs, options={"flat": 0})                                                    # the stack walk in the same workgroup shape
+        col3, _ = gs0.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
+        assert gs0.flags()["onchip"] and not gs0.flags()["flat"]
+        assert_bits_equal(col3, ocol, "%s: stack walk" % name)
+    # 356 triangles: LDS-resident only in 16-wave workgroups, stack walk (too many nodes for FLAT)
+    cfg = scenes.blob_in_box(os.path.join(scene_dir, "blob2"), 40, 24, 4, 6, subdiv=2, name="blob2")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    i = hs.info
+    assert 300 < i["n_tris"] < 400
+    ocol, ocnt, _ = osc.render(integrator=integrator, counters=True, threads=8)
+    col, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator)
+    assert gs.flags()["onchip"] and not gs.flags()["flat"], gs.flags()
+    assert_bits_equal(col, ocol, "356 triangles in 16-wave workgroups")
+    col2, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator, counters=True)
+    assert np.array_equal(cnt, ocnt)
+    assert_bits_equal(col2, ocol, "356 triangles, counting kernel")
