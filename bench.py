@@ -88,9 +88,11 @@ def kernel_name(flags, variant):
         if flags.get("simple"):
             return "pt::megakernel_hbm_simple<0>"
         return "pt::megakernel_hbm<0, false, %s, %s, false>" % (_tf(flags["culling"]), _tf(flags["refill"]))
+    if flags.get("flat_pair"):
+        return "pt::megakernel_flat2<0>"
     if flags.get("simple"):
-        return "pt::megakernel<0, false, false, true, false, true, true>"
-    return "pt::megakernel<0, false, false, %s, %s, %s, false>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))
+        return "pt::megakernel<0, false, false, true, false, true, true, 1>"
+    return "pt::megakernel<0, false, false, %s, %s, %s, false, 1>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))
 
 
 def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):

@@ -72,6 +72,7 @@ struct pt_scene {
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
+    int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 for scenes of at most 64 nodes / triangles, 2 also the 128-bit form (65..128: measured slower, A/B only)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0;
@@ -553,8 +554,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         else if (s->flatWanted == 2) P.flat = 2;           // 65..128: loses to the stack walk from ~80 triangles on (profiles/r02_flat_crossover.jsonl)
     }
     P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || (hbm && simpleHbm)) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
+    if (P.flat == 1 && P.simple && s->flat2Wanted && integrator == PT_UNIDIRECTIONAL && !count && useMIS) P.flat = 3;   // ... and the pair form of FLAT
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
+    s->lastLaunchFlat2 = (P.flat == 3) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? wavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -740,7 +743,7 @@ struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
-    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -772,6 +775,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 14: s->cull = v != 0; break;
         case 15: s->spec = v; break;
         case 16: s->simpleWanted = v != 0; break;
+        case 17: s->flat2Wanted = v; break;
     }
     return 0;
 }
@@ -796,6 +800,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 14: *out = s->cull; break;
         case 15: *out = s->spec; break;
         case 16: *out = s->simpleWanted; break;
+        case 17: *out = s->flat2Wanted; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;
@@ -807,7 +812,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0) | (s->lastLaunchFlat2 ? 256 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

@@ -336,7 +336,8 @@ PT_DEV void megakernel_body(const KParams& P) {
         const bool hasShadow = DEFER && (ps.flags & kShadowPending) != 0;
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
-        if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+        if constexpr (DEFER && FLAT) trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c, P.cacheNodes);
+        else if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
         else if constexpr (FLAT) {
             trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes);
 #ifdef PT_DIAG_DOUBLE_CLOSEST       // cost measurement only: the closest-hit traversal run twice, same result
@@ -423,6 +424,16 @@ megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
 megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE>(P); }
+
+// FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): SIMPLE scenes of at most 64 nodes / triangles, MIS integrator,
+// DEFER logic step; the wave's "stack" area is the 25 x 64-word scratch of the dealt-out tests.
+constexpr int kStackFlat2 = 25;
+template <int INTEG>
+__global__ void __launch_bounds__(1024)
+#if PT_MIN_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
+#endif
+megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, true, 1>(P); }
 
 // The SIMPLE production kernel for scenes in HBM: 8 waves per SIMD, 16-wave workgroups (pt_params.h).
 template <int INTEG>

@@ -617,6 +617,158 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     wave_lds_sync();                                              // the scratch becomes the stack again
 }
 
+// ---- FLAT for a PAIR of rays per lane (DEFER logic step): the shadow ray of the bounce just shaded and the extension ray
+// that continues the path share ONE lockstep node walk (node fetch, child refs, loop control paid once for both), and
+// their triangle tests are dealt out over the wave together. A shadow ray needs no order at all when no triangle of the
+// scene is a MAT_LEAF (NOLEAF scenes: any hit below max_t occludes), the extension ray is resolved as in
+// trace_closest_flat. At most 64 internal nodes / triangles. Scratch: 25 x 64 words of the wave's stack area:
+//   entry v = lane (extension ray) or 64 + lane (shadow ray): o, d, max_t, triangle mask (9 fields x 128), exclusive
+//   prefix (128), the two u64 keys of the extension rays (2 x 128 words), the occlusion flags (64).
+template <int N>
+PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>& st, bool hasShadow, V3 so, V3 sd, float smaxt,
+                            bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal) {
+    static_assert(N >= 25, "the scratch layout needs 25 x 64 words of the wave's stack area");
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const int lane = (int)(threadIdx.x & 63u);
+    lds_i32* Wd = st.lds - lane;
+    constexpr int kPre = 9 * 128, kKeys = kPre + 128, kOcc = kKeys + 256;
+    const V3 invE = inv3(ed), invS = inv3(sd);
+    // 1. one lockstep node walk for both rays
+    uint64_t tmE = 0ull, tmS = 0ull;
+    if (S.rootRef < 0) { const uint64_t all = ~0ull >> (64 - S.nTris); tmE = hasExt ? all : 0ull; tmS = hasShadow ? all : 0ull; }
+    else {
+        uint64_t visE = hasExt ? 1ull << (uint32_t)S.rootRef : 0ull, visS = hasShadow ? 1ull << (uint32_t)S.rootRef : 0ull;
+        for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
+            const bool vE = ((visE >> i) & 1ull) != 0ull, vS = ((visS >> i) & 1ull) != 0ull;
+            if (__builtin_amdgcn_ballot_w64(vE || vS) == 0ull) continue;
+            const NodeData n = load_node<true>(S, C, i);
+            float t0, t1;
+            const bool eL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, eo, invE, t0) && vE;
+            const bool eR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, eo, invE, t1) && vE;
+            const bool sL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, so, invS, t0) && vS;
+            const bool sR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, so, invS, t1) && vS;
+            const int32_t left = __builtin_amdgcn_readfirstlane(f2i(n.d.x)), right = __builtin_amdgcn_readfirstlane(f2i(n.d.y));
+            const int32_t cntL = __builtin_amdgcn_readfirstlane(f2i(n.d.z)), cntR = __builtin_amdgcn_readfirstlane(f2i(n.d.w));
+            const uint64_t bL = left >= 0 ? 1ull << (uint32_t)left : (~0ull >> (64 - cntL)) << (uint32_t)(~left);
+            const uint64_t bR = right >= 0 ? 1ull << (uint32_t)right : (~0ull >> (64 - cntR)) << (uint32_t)(~right);
+            if (left >= 0) { visE |= eL ? bL : 0ull; visS |= sL ? bL : 0ull; } else { tmE |= eL ? bL : 0ull; tmS |= sL ? bL : 0ull; }
+            if (right >= 0) { visE |= eR ? bR : 0ull; visS |= sR ? bR : 0ull; } else { tmE |= eR ? bR : 0ull; tmS |= sR ? bR : 0ull; }
+        }
+    }
+    // 2. deal the tests of all 128 rays out: extension rays first (entries 0..63), then shadow rays (64..127)
+    auto scan = [&](int v, int& total) {                          // inclusive prefix sum over the wave
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+        const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47);
+        v += (lane >= 16 ? r0 : 0) + (lane >= 32 ? r1 : 0) + (lane >= 48 ? r2 : 0);
+        total = __builtin_amdgcn_readlane(v, 63);
+        return v;
+    };
+    const int nE = (int)__builtin_popcountll(tmE), nS = (int)__builtin_popcountll(tmS);
+    int totalE, totalS;
+    const int preE = scan(nE, totalE) - nE, preS = totalE + scan(nS, totalS) - nS;
+    const int total = totalE + totalS;
+    auto put = [&](int v, V3 ro, V3 rd, float mt, uint64_t tm, int pre) {
+        Wd[0 * 128 + v] = __builtin_bit_cast(int32_t, ro.x); Wd[1 * 128 + v] = __builtin_bit_cast(int32_t, ro.y); Wd[2 * 128 + v] = __builtin_bit_cast(int32_t, ro.z);
+        Wd[3 * 128 + v] = __builtin_bit_cast(int32_t, rd.x); Wd[4 * 128 + v] = __builtin_bit_cast(int32_t, rd.y); Wd[5 * 128 + v] = __builtin_bit_cast(int32_t, rd.z);
+        Wd[6 * 128 + v] = __builtin_bit_cast(int32_t, mt);
+        Wd[7 * 128 + v] = (int32_t)(uint32_t)tm; Wd[8 * 128 + v] = (int32_t)(uint32_t)(tm >> 32);
+        Wd[kPre + v] = pre;
+    };
+    put(lane, eo, ed, 999999.0f, tmE, preE);
+    put(64 + lane, so, sd, smaxt, tmS, preS);
+    lds_u64* kLo = (lds_u64*)(Wd + kKeys);
+    lds_u64* kHi = (lds_u64*)(Wd + kKeys + 128);
+    kLo[lane] = ~0ull; kHi[lane] = ~0ull;
+    Wd[kOcc + lane] = 0;
+    wave_lds_sync();
+    const int per = (total + 63) >> 6;
+    int p = lane * per;
+    const int pEnd = (p + per < total) ? p + per : total;
+    int l = 0;
+    uint64_t rem = 0ull;
+    V3 ro = v3(0.0f), rd = v3(0.0f);
+    float rmax = 0.0f;
+    auto fetch = [&](int v) {
+        rem = (uint64_t)(uint32_t)Wd[7 * 128 + v] | ((uint64_t)(uint32_t)Wd[8 * 128 + v] << 32);
+        ro = v3(__builtin_bit_cast(float, Wd[0 * 128 + v]), __builtin_bit_cast(float, Wd[1 * 128 + v]), __builtin_bit_cast(float, Wd[2 * 128 + v]));
+        rd = v3(__builtin_bit_cast(float, Wd[3 * 128 + v]), __builtin_bit_cast(float, Wd[4 * 128 + v]), __builtin_bit_cast(float, Wd[5 * 128 + v]));
+        rmax = __builtin_bit_cast(float, Wd[6 * 128 + v]);
+    };
+    if (p < pEnd) {
+        for (int sft = 64; sft; sft >>= 1) { const int cand = l + sft; if (Wd[kPre + cand] <= p) l = cand; }     // owner of test p among the 128 entries
+        fetch(l);
+        rem &= ~((1ull << select64(rem, p - Wd[kPre + l])) - 1ull);
+    }
+    for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
+        if (p < pEnd) {
+            while (rem == 0ull) { l++; fetch(l); }                // next ray that has tests (there is one: p < total)
+            const int ti = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            const TriData q = load_tri<true>(S, C, ti);
+            float t, u, v;
+            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), ro, rd, t, u, v);
+            if (ok && (t < rmax)) {
+                if (l < 64) {
+                    const uint64_t tb = (uint64_t)f2u(t) << 32;
+                    __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(63 - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else Wd[kOcc + (l - 64)] = 1;                    // NOLEAF: any hit below max_t ends the shadow ray (BVHShadowRay returns 0)
+            }
+            p++;
+        }
+    }
+    wave_lds_sync();
+    // 3. results: the shadow ray's throughput, the extension ray's winner (ties as in trace_closest_flat)
+    thr = (hasShadow && Wd[kOcc + lane] != 0) ? v3(0.0f) : v3(1.0f);
+    hit.tri = -1; hit.t = 0.0f; hit.u = 0.0f; hit.v = 0.0f; hit.material = 0;
+    if (hasExt) {
+        const uint64_t a = kLo[lane], b = kHi[lane];
+        if (a != ~0ull) {
+            int win = (int)(uint32_t)a;
+            const int last = 63 - (int)(uint32_t)b;
+            if (win != last) {
+                const uint32_t tmin = (uint32_t)(a >> 32);
+                uint64_t tied = 0ull;
+                for (uint64_t rest = tmE; rest; rest &= rest - 1ull) {
+                    const int ti = __builtin_ctzll(rest);
+                    const TriData q = load_tri<true>(S, C, ti);
+                    float t, u, v;
+                    const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), eo, ed, t, u, v);
+                    if (ok && (t < 999999.0f) && f2u(t) == tmin) tied |= 1ull << ti;
+                }
+                int32_t ref = S.rootRef;
+                int lo = 0;
+                while (ref >= 0) {
+                    const NodeData nd = load_node<true>(S, C, ref);
+                    const int mid = lo + f2i(nd.d.z), hi = mid + f2i(nd.d.w);
+                    const uint64_t inL = tied & ((~0ull >> (64 - (mid - lo))) << lo), inR = tied & ((~0ull >> (64 - (hi - mid))) << mid);
+                    bool goLeft = inR == 0ull;
+                    if (inL != 0ull && inR != 0ull) {
+                        float tL, tR;
+                        slab(nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, eo, invE, tL);
+                        slab(nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, eo, invE, tR);
+                        goLeft = tL < tR;
+                    }
+                    ref = goLeft ? f2i(nd.d.x) : f2i(nd.d.y);
+                    if (!goLeft) lo = mid;
+                    tied = goLeft ? inL : inR;
+                }
+                win = __builtin_ctzll(tied);
+            }
+            const TriData q = load_tri<true>(S, C, win);
+            float t, u, v;
+            moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), eo, ed, t, u, v);
+            hit.t = t; hit.u = u; hit.v = v;
+            hit.tri = (int32_t)(f2u(q.e.y) & 0x7fffffffu);
+            hit.material = f2i(q.e.z);
+        }
+    }
+    wave_lds_sync();
+}
+
 // ---- unified per-lane traverser -------------------------------------------------------------
 // The same two traversals as above as ONE resumable state machine, so that a lane can run its
 // rays back to back inside a single loop: the megakernel traces a bounce's shadow ray and the next

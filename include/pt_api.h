@@ -181,7 +181,8 @@ float pt_last_kernel_ms(pt_scene* scene);
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
  * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing), bit 6 = it used the FLAT
  * closest-hit traversal (LDS-resident scenes with at most 64 nodes and triangles), bit 7 = it used the SIMPLE bounce
- * (every triangle an untextured MAT_DIFFUSE: one arm per dispatcher, no medium stack). For labelling measurements. */
+ * (every triangle an untextured MAT_DIFFUSE: one arm per dispatcher, no medium stack), bit 8 = the pair form of FLAT
+ * (shadow + extension ray in one pass). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a
@@ -196,6 +197,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1|2          FLAT closest-hit traversal: off / LDS-resident scenes of at most 64 nodes and triangles (default) /
  *                         also its 128-bit form for 65..128 (measured slower than the stack walk from ~80 triangles on)
+ *   "flat2" 0|1           SIMPLE FLAT scenes, MIS integrator: shadow ray and next extension ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)

@@ -635,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -786,3 +786,33 @@ def test_flat_128_and_larger_workgroups(api, oracle, gpu_ready, scene_dir, integ
     col2, cnt = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"], integrator=integrator, counters=True)
     assert np.array_equal(cnt, ocnt)
     assert_bits_equal(col2, ocol, "356 triangles, counting kernel")
+
+
+def test_flat_pair_kernel(api, oracle, gpu_ready, scene_dir):
+    """pt_trace.h trace_pair_flat ("flat2" = 1): SIMPLE scenes of at most 64 nodes / triangles trace the shadow ray of a bounce
+    and the next extension ray in ONE FLAT pass (shared lockstep node walk, tests of both rays dealt out together, DEFER
+    logic step). Golden Cornell frames, a doubled box (every hit on it a tie), the C1 configuration — bit for bit."""
+    from cudapathtracer_amd import scenes
+    for case in ("cornell32_mis", "cornell64_mis"):
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        sc = api.Scene(hs, options={"flat2": 1, "slice_iters": 8, "sched_mask": 3})
+        for _ in range(2):
+            col, _ = sc.render(hs.camera(), int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]))
+            assert sc.flags()["flat"] and sc.flags()["simple"] and sc.flags()["flat_pair"], sc.flags()
+            assert_bits_equal(col, g["colors"], case + " flat2")
+        naive = np.load(os.path.join(GOLDEN, "cornell32_naive.npz"))                 # the naive integrator has no shadow rays: plain FLAT
+    cfgs = [scenes.cornell(os.path.join(scene_dir, "p2twin"), 40, 24, 6, 16, doubled=17, ceiling_light=True, name="p2twin")["config"],
+            scenes.cornell(os.path.join(scene_dir, "p2c1"), 256, 256, 16, 4, name="p2c1")["config"],
+            scenes.cornell(os.path.join(scene_dir, "p2x2"), 45, 27, 5, 9, extra_boxes=2, name="p2x2")["config"]]
+    for cfg in cfgs:
+        gs, hs, osc = _scene_pair(api, oracle, cfg, options={"flat2": 1})
+        i = hs.info
+        ocol, _, _ = osc.render(threads=8)
+        col, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"])
+        assert gs.flags()["flat"] and gs.flags()["simple"] and gs.flags()["flat_pair"], gs.flags()
+        assert_bits_equal(col, ocol, cfg)
+        g0 = api.Scene(hs, options={"flat2": 0})                                     # one ray per pass: the round-1 shape of FLAT
+        col0, _ = g0.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"])
+        assert g0.flags()["flat"] and not g0.flags()["flat_pair"]
+        assert_bits_equal(col0, ocol, cfg + " flat2=0")
