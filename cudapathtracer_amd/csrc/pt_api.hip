@@ -520,7 +520,11 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     // ... of which the SIMPLE instantiation (diffuse-only scenes; timed launches with the resumable traversal) runs at 8 waves per SIMD
     const bool simpleHbm = !onchip && !deferred && s->wavesHbmOk && s->simpleOk && s->simpleWanted && s->refill && !s->cull && !s->armless && !count;
     const int wavesHbm = simpleHbm ? kWavesHbmSimple : kWavesHbm;
-    const bool hbm = !onchip && !deferred && s->wavesHbmOk && (s->wavesHbmForce || (long long)t.count * 4 >= (long long)s->numCU * 4 * wavesHbm * 5);
+    // (the SIMPLE kernel's eight waves per SIMD pay from ~3/4 of its 8192 slots on — a 1/4 share of a 1080p frame: 201 vs 269 ms on
+    //  the 263 k-triangle scene — the generic kernel's six from 5/4 of its 6144, profiles/r02_sched_shards.log)
+    const long long slotsHbm = (long long)s->numCU * 4 * wavesHbm;
+    const bool hbm = !onchip && !deferred && s->wavesHbmOk &&
+                     (s->wavesHbmForce || (simpleHbm ? (long long)t.count * 4 >= slotsHbm * 3 : (long long)t.count * 4 >= slotsHbm * 5));
     const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
     const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
@@ -553,7 +557,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         if (s->nInternal <= 64 && s->nTrisPacked <= 64) P.flat = 1;
         else if (s->flatWanted == 2) P.flat = 2;           // 65..128: loses to the stack walk from ~80 triangles on (profiles/r02_flat_crossover.jsonl)
     }
-    P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || (hbm && simpleHbm)) ? 1 : 0;     // the two instantiations that have the SIMPLE bounce
+    // the instantiations that have the SIMPLE bounce: FLAT, the production kernel for scenes in HBM and its 4-wave form (small shares)
+    P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || simpleHbm) ? 1 : 0;
     if (P.flat == 1 && P.simple && s->flat2Wanted && integrator == PT_UNIDIRECTIONAL && !count && useMIS) P.flat = 3;   // ... and the pair form of FLAT
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
