@@ -55,7 +55,8 @@ struct DevBuf {
 
 struct pt_scene {
     int device = 0;
-    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals;
+    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves;
+    int nLeaves = 0;                                  // FLAT scenes: the leaf table (pt_trace.h: visited(leaf) == slab(leaf's own box))
     DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
     DevBuf wfState, wfCtl, wfCtr, wfSpill;            // wavefront variant
     int variant = 0;                                  // 0 megakernel, 1 wavefront (pt_set_variant)
@@ -72,6 +73,7 @@ struct pt_scene {
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
+    bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 for scenes of at most 64 nodes / triangles, 2 also the 128-bit form (65..128: measured slower, A/B only)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
@@ -100,7 +102,7 @@ static int queue_error(pt_scene* s);
 // size (in waves) that holds the scene, 0 if none does.
 static int scene_onchip_wg(const pt_scene* s) {
     if (!s->onchipOk || s->nTrisPacked <= 0 || s->ds.stackSpill != 0) return 0;
-    const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked);
+    const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked, s->nTrisPacked <= 128 ? s->nTrisPacked : 0);   // (+ room for the FLAT kernels' leaf table: at most one leaf per triangle)
     for (int wg = 4; wg <= 16; wg *= 2)
         if (geom <= (size_t)kCacheBytes * (wg / 4) && (kAttrCacheBytes == 0 || rec <= (size_t)kAttrCacheBytes * (wg / 4))) return wg;
     return 0;
@@ -123,7 +125,7 @@ int pt_device_count(void) {
 
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
-    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals,
+    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals, &s->leaves,
                      &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->queue, &s->left, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -377,6 +379,23 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         if (ok && nInternal > 0) ok = first[0] == 0 && pn[0].pad0 + pn[0].pad1 == nT;
         if (ok && nInternal > 0) HIP_OK(hipMemcpy(s->nodes.p, pn.data(), (size_t)nInternal * sizeof(PNode), hipMemcpyHostToDevice));
         s->flatOk = ok;
+        s->nLeaves = 0;
+        if (ok && nInternal > 0) {                              // the leaf table: every leaf child's box and triangle range
+            std::vector<PLeaf> lf;
+            for (int i = 0; i < nInternal; i++) {
+                const int32_t* ref = &pn[i].left;
+                for (int k = 0; k < 2; k++) {
+                    if (ref[k] >= 0) continue;
+                    PLeaf L;
+                    const float* mn = k == 0 ? pn[i].lmin : pn[i].rmin; const float* mx = k == 0 ? pn[i].lmax : pn[i].rmax;
+                    for (int a = 0; a < 3; a++) { L.mn[a] = mn[a]; L.mx[a] = mx[a]; }
+                    L.first = ~ref[k]; L.count = ref[2 + k];
+                    lf.push_back(L);
+                }
+            }
+            if (int r = upload(s->leaves, lf.data(), lf.size() * sizeof(PLeaf))) return r;
+            s->nLeaves = (int)lf.size();
+        }
     }
     return 0;
 }
@@ -542,7 +561,9 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     if (onchip) { P.cacheNodes = s->nInternal; P.cacheTris = s->nTrisPacked; }      // the whole scene, in workgroups large enough to hold it
     P.cacheAttrs = P.cacheMats = P.cacheLights = 0;
+    P.cacheLeaves = 0; P.leaves = nullptr;
     if (onchip && kAttrCacheBytes > 0) { P.cacheAttrs = s->nTrisPacked; P.cacheMats = s->nMats; P.cacheLights = s->nLightsPacked; }   // the bounce's records in LDS as well
+    if (onchip && kAttrCacheBytes > 0 && s->flatOk && s->leafBoxes && s->nLeaves > 0) { P.cacheLeaves = s->nLeaves; P.leaves = (const PLeaf*)s->leaves.p; }
     P.wgWaves = wgWaves;
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
     P.xcdBands = s->xcdBands ? 1 : 0;
@@ -748,7 +769,7 @@ struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
-    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -781,6 +802,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 15: s->spec = v; break;
         case 16: s->simpleWanted = v != 0; break;
         case 17: s->flat2Wanted = v; break;
+        case 18: s->leafBoxes = v != 0; break;
     }
     return 0;
 }
@@ -806,6 +828,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 15: *out = s->spec; break;
         case 16: *out = s->simpleWanted; break;
         case 17: *out = s->flat2Wanted; break;
+        case 18: *out = s->leafBoxes; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

@@ -163,6 +163,13 @@ struct __attribute__((aligned(16))) PMat {
 static_assert(sizeof(PMat) == 96, "PMat");
 constexpr uint32_t kMatHasTexture = 1, kMatHasTransMap = 2, kMatSpecular = 4, kMatBoundary = 8;
 
+// FLAT kernels: one record per LEAF of the tree — the leaf's own box (as stored with its parent) and its triangle range.
+struct __attribute__((aligned(16))) PLeaf {
+    float mn[3], mx[3];
+    int32_t first, count;
+};
+static_assert(sizeof(PLeaf) == 32, "PLeaf");
+
 struct DeviceScene {
     const PNode* nodes;
     const PTri* tris;

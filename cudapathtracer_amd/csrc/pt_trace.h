@@ -476,10 +476,24 @@ template <int W> struct BitSet {
     }
 };
 
+// Which leaves does a ray visit? The reference descends into a child iff its box passes aabbIntersect, so a leaf is visited
+// iff EVERY box on its root path passes. Those boxes are nested exactly (a parent's box is the float-wise min / max of its
+// children's), and slab() is monotone in the box: x -> RN(x - o) and y -> RN(y * inv) are monotone maps, min / max keep
+// order, so per axis the parent's t-interval contains the child's, the parent's tmin is <= and its tmax >= the child's —
+// if the child's box passes (`tmax >= tmin && tmax > 0`), the parent's does. Hence: visited(leaf) == slab(leaf's own box),
+// with no tree walk at all — PROVIDED no NaN enters, i.e. every 1 / d component is finite and non-zero (a zero or denormal
+// direction component gives inf, and 0 * inf = NaN is dropped by v_min / v_max in a way that is not monotone). A wave in
+// which some ray fails that test takes the lockstep node walk for that pass (rare: a direction component must be exactly 0).
+PT_DEV bool inv_is_regular(V3 inv) {
+    const float a = __builtin_fabsf(inv.x), b = __builtin_fabsf(inv.y), cc = __builtin_fabsf(inv.z);
+    return a > 0.0f && a < __builtin_inff() && b > 0.0f && b < __builtin_inff() && cc > 0.0f && cc < __builtin_inff();     // false for NaN too
+}
+
 // All 64 lanes call this together; `active` says who has a ray. PNode.pad0 / pad1 hold the number of triangles
 // below the left / right child (patched in by the host for scenes that qualify, pt_api.hip).
 template <int N, int W = 1>
-PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool active, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nInternal) {
+PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool active, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nInternal,
+                               lds_cf4* leaves = nullptr, int nLeaves = 0) {
     static_assert(N >= 11 + 2 * W, "the scratch layout needs (11 + 2 W) x 64 words of the wave's stack");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef BitSet<W> Set;
@@ -491,7 +505,14 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     // 1. lockstep node walk
     Set tm = Set::zero();
     if (S.rootRef < 0) { if (active) tm = Set::range(0, S.nTris); }      // the root is the only leaf
-    else {
+    else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64(active && !inv_is_regular(inv)) == 0ull) {
+        for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes (see inv_is_regular): wave-uniform loop
+            const f4v a = leaves[2 * k], b = leaves[2 * k + 1];   // uniform address: LDS broadcasts
+            float t0;
+            const bool hitL = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, t0) && active;
+            tm.or_if(hitL, Set::range(__builtin_amdgcn_readfirstlane(f2i(b.z)), __builtin_amdgcn_readfirstlane(f2i(b.w))));
+        }
+    } else {
         Set vis = Set::zero();
         if (active) vis = Set::range(S.rootRef, 1);
         for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
@@ -626,7 +647,7 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
 //   prefix (128), the two u64 keys of the extension rays (2 x 128 words), the occlusion flags (64).
 template <int N>
 PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>& st, bool hasShadow, V3 so, V3 sd, float smaxt,
-                            bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal) {
+                            bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal, lds_cf4* leaves = nullptr, int nLeaves = 0) {
     static_assert(N >= 25, "the scratch layout needs 25 x 64 words of the wave's stack area");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     const int lane = (int)(threadIdx.x & 63u);
@@ -636,7 +657,17 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     // 1. one lockstep node walk for both rays
     uint64_t tmE = 0ull, tmS = 0ull;
     if (S.rootRef < 0) { const uint64_t all = ~0ull >> (64 - S.nTris); tmE = hasExt ? all : 0ull; tmS = hasShadow ? all : 0ull; }
-    else {
+    else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64((hasExt && !inv_is_regular(invE)) || (hasShadow && !inv_is_regular(invS))) == 0ull) {
+        for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes, both rays (see inv_is_regular)
+            const f4v a = leaves[2 * k], b = leaves[2 * k + 1];
+            float t0;
+            const bool eH = slab(a.x, a.y, a.z, a.w, b.x, b.y, eo, invE, t0) && hasExt;
+            const bool sH = slab(a.x, a.y, a.z, a.w, b.x, b.y, so, invS, t0) && hasShadow;
+            const int first = __builtin_amdgcn_readfirstlane(f2i(b.z)), cnt = __builtin_amdgcn_readfirstlane(f2i(b.w));
+            const uint64_t m = (~0ull >> (64 - cnt)) << (uint32_t)first;
+            tmE |= eH ? m : 0ull; tmS |= sH ? m : 0ull;
+        }
+    } else {
         uint64_t visE = hasExt ? 1ull << (uint32_t)S.rootRef : 0ull, visS = hasShadow ? 1ull << (uint32_t)S.rootRef : 0ull;
         for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
             const bool vE = ((visE >> i) & 1ull) != 0ull, vS = ((visS >> i) & 1ull) != 0ull;

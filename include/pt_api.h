@@ -197,6 +197,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1|2          FLAT closest-hit traversal: off / LDS-resident scenes of at most 64 nodes and triangles (default) /
  *                         also its 128-bit form for 65..128 (measured slower than the stack walk from ~80 triangles on)
+ *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
  *   "flat2" 0|1           SIMPLE FLAT scenes, MIS integrator: shadow ray and next extension ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)

@@ -635,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -816,3 +816,30 @@ def test_flat_pair_kernel(api, oracle, gpu_ready, scene_dir):
         col0, _ = g0.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"])
         assert g0.flags()["flat"] and not g0.flags()["flat_pair"]
         assert_bits_equal(col0, ocol, cfg + " flat2=0")
+
+
+def test_flat_leaf_boxes_and_degenerate_directions(api, oracle, gpu_ready, scene_dir):
+    """The FLAT kernels decide which leaves a ray visits from the leaves' own boxes (nested boxes + a monotone slab test:
+    pt_trace.h) — unless a ray of the wave has a zero direction component, where 0 * inf = NaN breaks the argument and the
+    wave walks the nodes. Both forms against the oracle, and a camera that looks exactly along -z from the room's centre
+    line with a zero-aperture lens... whose primary rays through the image centre column / row have an exact 0 component."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.cornell(os.path.join(scene_dir, "lb"), 41, 25, 6, 9, name="lb")["config"]           # odd size: a centre column and row exist
+    hs = api.HostScene(cfg)
+    osc = oracle.OracleScene(cfg)
+    cam = api.Camera.NotPinhole((0.0, 0.0, 1.0), 41, 25, (0.0, 0.0, 0.0), 60.0, 0.0, 1.0)              # aperture 0: two uniforms per camera ray, no lens offset
+    cb = np.frombuffer(cam.tobytes(), np.uint8)
+    for integ in (0, 2):
+        ocol, _, _ = osc.render(camera=cb, width=41, height=25, spp=6, max_depth=9, integrator=integ, threads=8)
+        for opts in ({}, {"leaf_boxes": 0}, {"flat2": 0}, {"flat2": 0, "leaf_boxes": 0}, {"simple": 0}):
+            sc = api.Scene(hs, options=opts)
+            col, _ = sc.render(cam, 41, 25, 6, 9, integrator=integ)
+            assert sc.flags()["flat"], sc.flags()
+            assert_bits_equal(col, ocol, "leaf boxes %s integrator %d" % (opts, integ))
+    # rays with exact zero components through the probes: axis-parallel directions from inside the room
+    rays = np.array([[0.0, 0.0, 0.5, 0.0, 0.0, -1.0], [0.1, -0.2, 0.0, 1.0, 0.0, 0.0], [0.1, -0.2, -0.5, 0.0, 1.0, 0.0],
+                     [0.0, 0.0, 0.0, 0.0, -1.0, 0.0], [0.3, 0.1, -0.2, -1.0, 0.0, 0.0], [0.2, 0.0, 0.3, 0.70710677, 0.0, -0.70710677]], np.float32)
+    gi, gf, _ = api.Scene(hs).trace_closest(rays)
+    oi, of, _ = osc.trace_closest(rays)
+    assert np.array_equal(gi, oi)
+    assert_bits_equal(gf, of, "axis-parallel rays")
