@@ -76,7 +76,7 @@ struct pt_scene {
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
-    bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 for scenes of at most 64 nodes / triangles, 2 also the 128-bit form (65..128: measured slower, A/B only)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
+    bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 (or 2) on: scenes of at most 128 nodes / triangles (64- or 128-bit masks)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0;
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
@@ -575,8 +575,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
     P.flat = 0;                                             // 1: FLAT with 64-bit masks, 2: with 128-bit masks
     if (onchip && s->flatOk && s->flatWanted && !deferred && !P.refill) {
-        if (s->nInternal <= 64 && s->nTrisPacked <= 64) P.flat = 1;
-        else if (s->flatWanted == 2) P.flat = 2;           // 65..128: loses to the stack walk from ~80 triangles on (profiles/r02_flat_crossover.jsonl)
+        P.flat = (s->nInternal <= 64 && s->nTrisPacked <= 64) ? 1 : 2;     // 65..128: +17-20 % over the stack walk with the leaf-box form (profiles/r02_flat_crossover.jsonl)
     }
     // the instantiations that have the SIMPLE bounce: FLAT, the production kernel for scenes in HBM and its 4-wave form (small shares)
     P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || simpleHbm) ? 1 : 0;

@@ -195,8 +195,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * process renders cannot be steered from its environment. Only "culling" (= pt_set_culling) can reach the image; all
  * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
- *   "flat" 0|1|2          FLAT closest-hit traversal: off / LDS-resident scenes of at most 64 nodes and triangles (default) /
- *                         also its 128-bit form for 65..128 (measured slower than the stack walk from ~80 triangles on)
+ *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
  *   "flat2" 0|1           SIMPLE FLAT scenes, MIS integrator: shadow ray and next extension ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)

@@ -749,7 +749,7 @@ def test_simple_bounce_specialisation(api, oracle, gpu_ready, scene_dir):
 @pytest.mark.parametrize("integrator", [0, 2])
 def test_flat_128_and_larger_workgroups(api, oracle, gpu_ready, scene_dir, integrator):
     """LDS-resident scenes beyond Cornell: 65-128 triangles run the FLAT traversal with 128-bit masks (incl. a doubled box:
-    every hit on it is a two-way tie; opt-in, "flat" = 2), and scenes whose records need more LDS than a 4-wave workgroup's share run in
+    every hit on it is a two-way tie), and scenes whose records need more LDS than a 4-wave workgroup's share run in
     workgroups of 8 or 16 waves that hold one copy of the scene — FLAT up to 128 triangles, the stack walk beyond.
     Timed and counting kernels against the oracle, bit for bit."""
     from cudapathtracer_amd import scenes
@@ -759,7 +759,7 @@ def test_flat_128_and_larger_workgroups(api, oracle, gpu_ready, scene_dir, integ
              ("x7", dict(extra_boxes=7, ceiling_light=True), True)]                                # 120 triangles
     for name, kw, want_flat in cases:
         cfg = scenes.cornell(os.path.join(scene_dir, "f128_" + name), 40, 24, 5, 7, name=name, **kw)["config"]
-        gs, hs, osc = _scene_pair(api, oracle, cfg, options={"flat": 2})          # the 128-bit form is opt-in (slower than the stack walk from ~80 triangles on)
+        gs, hs, osc = _scene_pair(api, oracle, cfg)
         i = hs.info
         assert 64 < i["n_tris"] <= 128, i["n_tris"]
         ocol, ocnt, _ = osc.render(integrator=integrator, counters=True, threads=8)
