@@ -55,7 +55,8 @@ struct DevBuf {
 
 struct pt_scene {
     int device = 0;
-    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves;
+    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves, wnodes;
+    int nWide = 0, wideStackNeed = 0; bool wideTried = false, wideWanted = false;   // the 4-wide collapsed tree of trace_resume_w4 ("wide" 1: opt-in, measured slower)
     int nLeaves = 0;                                  // FLAT scenes: the leaf table (pt_trace.h: visited(leaf) == slab(leaf's own box))
     DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
     DevBuf wfState, wfCtl, wfCtr, wfSpill;            // wavefront variant
@@ -125,7 +126,7 @@ int pt_device_count(void) {
 
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
-    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals, &s->leaves,
+    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals, &s->leaves, &s->wnodes,
                      &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->queue, &s->left, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -523,6 +524,66 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
     return 0;
 }
 
+// The reference tree collapsed to 4-wide nodes for trace_resume_w4 (pt_trace.h): same leaves, same float boxes, half the
+// levels. Built once per scene from the packed binary records (whoever packed them, host or device), numbered breadth-first
+// so that the first K wide nodes are the top of the tree (the LDS scene cache). A slot takes the place of an internal child
+// by that child's two children — the child with the largest box first — until the node has four slots or only leaves.
+static int ensure_wide(pt_scene* s) {
+    if (s->wideTried) return 0;
+    s->wideTried = true;
+    const int nI = s->nInternal;
+    if (nI <= 0 || s->ds.rootRef != 0) return 0;
+    std::vector<PNode> pn((size_t)nI);
+    HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nI * sizeof(PNode), hipMemcpyDeviceToHost));
+    struct Slot { float mn[3], mx[3]; int32_t ref; };
+    auto area = [](const Slot& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
+    auto children = [&](int32_t node, Slot out[2]) {
+        const PNode& p = pn[node];
+        for (int a = 0; a < 3; a++) { out[0].mn[a] = p.lmin[a]; out[0].mx[a] = p.lmax[a]; out[1].mn[a] = p.rmin[a]; out[1].mx[a] = p.rmax[a]; }
+        out[0].ref = p.left; out[1].ref = p.right;
+    };
+    std::vector<WNode> wn;
+    std::vector<int32_t> binaryOf;                    // wide node -> the binary node it was collapsed from
+    std::vector<int> need;                            // stack entries a traversal can hold below this node (filled bottom-up)
+    binaryOf.push_back(0);
+    for (size_t w = 0; w < binaryOf.size(); w++) {    // breadth-first: a wide node's internal slots are appended as they are met
+        Slot sl[4]; int n = 2;
+        children(binaryOf[w], sl);
+        while (n < 4) {
+            int best = -1; float bestA = -1.0f;
+            for (int i = 0; i < n; i++) if (sl[i].ref >= 0) { const float a = area(sl[i]); if (a > bestA) { bestA = a; best = i; } }
+            if (best < 0) break;
+            Slot two[2];
+            children(sl[best].ref, two);
+            sl[best] = two[0]; sl[n++] = two[1];
+        }
+        WNode W;
+        std::memset(&W, 0, sizeof(W));
+        for (int i = 0; i < 4; i++) {
+            if (i < n) {
+                W.mnx[i] = sl[i].mn[0]; W.mny[i] = sl[i].mn[1]; W.mnz[i] = sl[i].mn[2];
+                W.mxx[i] = sl[i].mx[0]; W.mxy[i] = sl[i].mx[1]; W.mxz[i] = sl[i].mx[2];
+                if (sl[i].ref >= 0) { W.ref[i] = (int32_t)binaryOf.size(); binaryOf.push_back(sl[i].ref); }
+                else W.ref[i] = sl[i].ref;
+            } else W.ref[i] = kRefNone;
+        }
+        W.pad[0] = n;
+        wn.push_back(W);
+        if (binaryOf.size() > (size_t)nI + 1) return fail(-1, "wide collapse: the packed tree is not a tree");
+    }
+    need.assign(wn.size(), 0);
+    int worst = 0;
+    for (int w = (int)wn.size() - 1; w >= 0; w--) {   // children come after their parent: bottom-up
+        int below = 0;
+        for (int i = 0; i < 4; i++) if (wn[w].ref[i] >= 0) below = std::max(below, need[wn[w].ref[i]]);
+        need[w] = (wn[w].pad[0] - 1) + below;         // the other slots wait on the stack while one is descended into
+        worst = std::max(worst, need[w]);
+    }
+    if (int r = upload(s->wnodes, wn.data(), wn.size() * sizeof(WNode))) return r;
+    s->nWide = (int)wn.size(); s->wideStackNeed = worst;
+    return 0;
+}
+
 // rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
 static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
                         uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool continueStreams) {
@@ -544,7 +605,12 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     const long long slotsHbm = (long long)s->numCU * 4 * wavesHbm;
     const bool hbm = !onchip && !deferred && s->wavesHbmOk &&
                      (s->wavesHbmForce || (simpleHbm ? (long long)t.count * 4 >= slotsHbm * 3 : (long long)t.count * 4 >= slotsHbm * 5));
-    const int spillEntries = hbm ? std::max(0, s->stackNeed - kStackLdsHbm) : s->ds.stackSpill;
+    bool wide = false;
+    if (hbm && simpleHbm && s->wideWanted) {
+        if (int r = ensure_wide(s)) return r;
+        wide = s->nWide > 0;
+    }
+    const int spillEntries = hbm ? std::max(0, (wide ? std::max(s->wideStackNeed, s->stackNeed) : s->stackNeed) - kStackLdsHbm) : s->ds.stackSpill;
     const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
     if (spillEntries > 0)
@@ -566,6 +632,8 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (onchip && kAttrCacheBytes > 0 && s->flatOk && s->leafBoxes && s->nLeaves > 0) { P.cacheLeaves = s->nLeaves; P.leaves = (const PLeaf*)s->leaves.p; }
     P.wgWaves = wgWaves;
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
+    P.wide = wide ? 1 : 0; P.wnodes = wide ? (const WNode*)s->wnodes.p : nullptr;
+    if (wide) P.cacheNodes = 2 * std::min(s->nWide, kCacheBytesHbmSimple / 128);            // wide nodes, counted in 64-byte halves
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
@@ -768,7 +836,7 @@ struct OptionRef { const char* name; int lo, hi; };
 const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
-    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1},
+    {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1}, {"wide", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -802,6 +870,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 16: s->simpleWanted = v != 0; break;
         case 17: s->flat2Wanted = v; break;
         case 18: s->leafBoxes = v != 0; break;
+        case 19: s->wideWanted = v != 0; break;
     }
     return 0;
 }
@@ -828,6 +897,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 16: *out = s->simpleWanted; break;
         case 17: *out = s->flat2Wanted; break;
         case 18: *out = s->leafBoxes; break;
+        case 19: *out = s->wideWanted; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

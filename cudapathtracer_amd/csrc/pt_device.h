@@ -163,6 +163,16 @@ struct __attribute__((aligned(16))) PMat {
 static_assert(sizeof(PMat) == 96, "PMat");
 constexpr uint32_t kMatHasTexture = 1, kMatHasTransMap = 2, kMatSpecular = 4, kMatBoundary = 8;
 
+// Wide node (4 children) of the collapsed tree the SIMPLE kernel for scenes in HBM may traverse (pt_trace.h: trace_resume_w4):
+// the children's boxes are the reference tree's own float boxes, axis-major; ref as in PNode (>= 0 wide node, < 0 leaf,
+// kRefNone = empty slot). One 128-byte line.
+struct __attribute__((aligned(128))) WNode {
+    float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
+    int32_t ref[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(WNode) == 128, "WNode");
+
 // FLAT kernels: one record per LEAF of the tree — the leaf's own box (as stored with its parent) and its triangle range.
 struct __attribute__((aligned(16))) PLeaf {
     float mn[3], mx[3];

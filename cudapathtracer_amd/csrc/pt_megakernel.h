@@ -141,7 +141,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, bool WIDE = false>
 PT_DEV void megakernel_body(const KParams& P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
@@ -150,7 +150,9 @@ PT_DEV void megakernel_body(const KParams& P) {
     constexpr bool ATTRLDS = ONCHIP && kAttrCacheBytes > 0;
     constexpr int kMedBytes = SIMPLE ? 0 : kMediumMax * 64;                 // SIMPLE kernels have no medium stack (pt_path.h)
     const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMedBytes) : 0;
-    const SceneCache SC = stage_scene_cache(S, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights, P.leaves, P.cacheLeaves);      // contains the only barrier
+    DeviceScene Sstage = S;
+    if (WIDE) Sstage.nodes = reinterpret_cast<const PNode*>(P.wnodes);       // the LDS scene cache of the WIDE kernel holds wide nodes (P.cacheNodes counts 64-byte halves)
+    const SceneCache SC = stage_scene_cache(Sstage, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights, P.leaves, P.cacheLeaves);      // contains the only barrier
     lds_cf4* leafTable = (lds_cf4*)(pt_smem + attrOff + P.cacheAttrs * 80 + P.cacheMats * 96 + P.cacheLights * 64);      // FLAT kernels (attrOff > 0 there)
     if constexpr (ATTRLDS) {
         // The bounce reads its records through S; pointing S at the LDS copies makes those loads ds_reads (the address
@@ -309,11 +311,35 @@ PT_DEV void megakernel_body(const KParams& P) {
                     if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, true);
                 }
                 const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
-                if (hasExt || hasShadow) ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+                if (hasExt || hasShadow) {
+                    bool irregular = false;
+                    if constexpr (WIDE) irregular = (hasExt && !inv_is_regular(inv3(ps.d))) || (hasShadow && !inv_is_regular(inv3(ps.sd)));
+                    if (WIDE && irregular) {
+                        // a zero direction component: the monotonicity argument behind the wide tree does not hold (0 * inf = NaN), so
+                        // this lane's rays take the reference traversal, here and now (rare: an axis-parallel direction)
+                        SceneCache none; none.nodes = nullptr; none.nNodes = 0; none.tris = nullptr; none.nTris = 0;
+                        thr = v3(1.0f);
+                        if (hasShadow) thr = trace_shadow_plain<false, STACKN, false, false, true>(S, none, ps.so, ps.sd, ps.smaxt, st, c);
+                        h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+                        if (hasExt) trace_closest_plain<false, STACKN, false, false>(S, none, ps.o, ps.d, 999999.0f, st, h, c);
+                        rs.flags = 0u;
+                    } else ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+                }
             }
             PT_STAMP(2);
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
+            if constexpr (WIDE) {
+                trace_resume_w4<STACKN>(S, SC, P.wnodes, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+                if (!(rs.flags & kRayBusy) && (rs.flags & kRayTie)) {
+                    // two triangles returned the SAME closest t: the reference keeps the one it visits first — its own traversal decides
+                    SceneCache none; none.nodes = nullptr; none.nNodes = 0; none.tris = nullptr; none.nTris = 0;
+                    trace_closest_plain<false, STACKN, false, false>(S, none, ps.o, ps.d, 999999.0f, st, h, c);
+                    rs.flags &= ~kRayTie;
+                }
+                PT_STAMP(1);
+                continue;
+            }
 #if PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
             if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
             else trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
@@ -439,6 +465,11 @@ __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
 #endif
 megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, true, 1>(P); }
+
+// ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace.h: trace_resume_w4).
+template <int INTEG>
+__global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
+megakernel_hbm_wide(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, true>(P); }
 
 // The SIMPLE production kernel for scenes in HBM: 8 waves per SIMD, 16-wave workgroups (pt_params.h).
 template <int INTEG>

@@ -61,6 +61,8 @@ struct KParams {
     int tileFirst, tileStride, tileCount, tilesX;
     int cacheNodes, cacheTris;     // scene-cache extent (PNodes / PTris staged in LDS per workgroup)
     int cacheAttrs, cacheMats, cacheLights;   // ONCHIP kernels: PAttr / PMat / PLight records staged behind the stacks (all or none; 0 = read from global memory)
+    int wide;                      // 1: megakernel_hbm_wide — the SIMPLE kernel for scenes in HBM on the 4-wide collapsed tree `wnodes`
+    const WNode* wnodes;
     int cacheLeaves;               // FLAT kernels: PLeaf records staged behind them (0 = none: the lockstep node walk)
     const PLeaf* leaves;
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation

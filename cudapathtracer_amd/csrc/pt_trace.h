@@ -1169,4 +1169,95 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }
 
+// ---- wide traversal (SIMPLE scenes in HBM) --------------------------------------------------------
+// visited(leaf) == slab(leaf's own box) (see inv_is_regular above) holds for ANY hierarchy whose inner boxes contain the
+// leaf boxes: a ray that passes a leaf's box passes every enclosing box (monotone slab test), and a leaf whose box it
+// misses is never tested. So the tree ABOVE the reference's leaves is ours to choose, and so is the visiting order, as
+// long as the RESULT is the reference's: the closest hit is the minimum t, and where two triangles return the same t the
+// reference keeps the one it visits first — that case is detected (a test that EQUALS the running minimum) and the ray is
+// re-traced on the reference's binary tree in the reference's order; a shadow ray of a scene without MAT_LEAF triangles
+// (NOLEAF) is occluded by any hit. Here: the reference tree collapsed to 4-wide nodes (host, pt_api.hip) — half the
+// dependent node fetches per ray, one full 128-byte line per fetch, children pushed in no particular order.
+// Rays with an irregular 1 / d (zero direction component) take the reference traversal as a whole.
+// MEASURED (profiles/r02_ab_wide.log), parity-green: 263 k triangles 752 -> 993 ms, 82 k 215 -> 253 ms — SLOWER. 28 dwords of
+// node per visit do not fit the 64 VGPRs this kernel runs best at (596 scratch instructions, many of them in the node loop),
+// and a visit fetches all four children's boxes whether or not the ray needs them. Opt-in ("wide" = 1) for the A/B.
+constexpr uint32_t kRayTie = 8u, kRaySlow = 16u;
+
+template <int N>
+PT_DEV void trace_resume_w4(const DeviceScene& S, const SceneCache& C, const WNode* __restrict__ W, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
+                            V3& thr, Hit& h, Ctr& c, Keep k) {
+    if (!(r.flags & kRayBusy)) return;
+    V3 o = r.o, d = r.d, inv = r.inv;
+    float max_t = r.max_t, min_t = r.min_t;
+    int32_t cur = r.cur;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, tie = (r.flags & kRayTie) != 0, busy = true;
+    const int nLdsW = C.nNodes >> 1;                               // the LDS scene cache holds the first nLdsW wide nodes (2 x 64 B each)
+    while (true) {
+        const int active = lanes_here();
+        if (active <= minBusy) break;
+        const int keepN = (active * k.node) >> 4;
+        while (cur >= 0) {
+            f4v mnx, mny, mnz, mxx, mxy, mxz, rf;
+            if (cur < nLdsW) { lds_cf4* p = C.nodes + cur * 8; mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5]; rf = p[6]; }
+            else { const f4v* p = reinterpret_cast<const f4v*>(W + cur); mnx = p[0]; mny = p[1]; mnz = p[2]; mxx = p[3]; mxy = p[4]; mxz = p[5]; rf = p[6]; }
+            int32_t next = kRefNone;
+            float tNext = 0.0f;                                     // the nearest hit child is descended into first (a shadow ray finds its occluder sooner)
+#define PT_W4_CHILD(K)                                                                                                    \
+            {                                                                                                               \
+                float tm_;                                                                                                  \
+                const int32_t ref_ = f2i(rf.K);                                                                             \
+                if (slab(mnx.K, mny.K, mnz.K, mxx.K, mxy.K, mxz.K, o, inv, tm_) && ref_ != kRefNone) {                      \
+                    const bool nearer_ = next == kRefNone || tm_ < tNext;                                                   \
+                    if (next != kRefNone) st.push(nearer_ ? next : ref_);                                                   \
+                    if (nearer_) { next = ref_; tNext = tm_; }                                                              \
+                }                                                                                                           \
+            }
+            PT_W4_CHILD(x) PT_W4_CHILD(y) PT_W4_CHILD(z) PT_W4_CHILD(w)
+#undef PT_W4_CHILD
+            cur = next != kRefNone ? next : (st.sp > 0 ? st.pop() : kRefNone);
+            if (lanes_here() <= keepN) break;
+        }
+        if (cur >= 0) continue;
+        if (cur == kRefNone) {
+            if (isShadow && extFollows) {                           // shadow ray done: start this lane's extension ray
+                isShadow = false; extFollows = false;
+                o = eo; d = ed; inv = inv3(d); max_t = 999999.0f;
+                cur = S.rootRef; st.sp = 0;
+                continue;
+            }
+            busy = false;
+            break;
+        }
+        int32_t ti = ~cur;
+        uint32_t idx;
+        bool occluded = false, more;
+        const int keepT = (lanes_here() * k.tri) >> 4;
+        do {
+            TriData q = load_tri<false>(S, C, ti);
+            idx = f2u(q.e.y);
+            float t, u, v;
+            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            if (isShadow) {
+                if (ok && (t < max_t)) { thr = v3(0.0f); occluded = true; break; }       // NOLEAF scene: any hit ends the ray
+            } else if (ok && (t < max_t)) {
+                if (t < min_t) {
+                    min_t = t; tie = false;
+                    h.t = t; h.u = u; h.v = v;
+                    h.tri = (int32_t)(idx & 0x7fffffffu);
+                    h.material = f2i(q.e.z);
+                } else if (t == min_t) tie = true;                 // the reference's visiting order decides: re-traced below
+            }
+            ti++;
+            more = !(idx & 0x80000000u);
+            if (more && lanes_here() <= keepT) break;
+        } while (more);
+        if (!occluded && more) { cur = ~ti; continue; }            // the rest of this leaf next time round
+        cur = (!occluded && st.sp > 0) ? st.pop() : kRefNone;
+        if (occluded) st.sp = 0;
+    }
+    r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur;
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | (tie ? kRayTie : 0u);
+}
+
 }  // namespace pt

@@ -196,6 +196,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
+ *   "wide" 0|1            SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes (0: measured 10-30 % slower)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
  *   "flat2" 0|1           SIMPLE FLAT scenes, MIS integrator: shadow ray and next extension ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)

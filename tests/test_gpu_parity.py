@@ -635,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 8, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -843,3 +843,25 @@ def test_flat_leaf_boxes_and_degenerate_directions(api, oracle, gpu_ready, scene
     oi, of, _ = osc.trace_closest(rays)
     assert np.array_equal(gi, oi)
     assert_bits_equal(gf, of, "axis-parallel rays")
+
+
+def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
+    """pt_trace.h trace_resume_w4: SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes, children in no
+    particular order; equal-t ties and rays with a zero direction component fall back to the reference traversal. A scene
+    whose every second quad is DOUBLED (each hit on them a two-way tie between different leaves), an axis-aligned camera
+    (primary rays with exact zero components), and a blob — against the oracle. Opt-in ("wide" = 1): measured slower."""
+    from cudapathtracer_amd import scenes
+    cfgs = [scenes.blob_in_box(os.path.join(scene_dir, "wblob4"), 64, 40, 3, 8, subdiv=4, name="wblob4")["config"],
+            scenes.cornell(os.path.join(scene_dir, "wtwin"), 48, 32, 4, 10, doubled=17, extra_boxes=7, ceiling_light=True, name="wtwin")["config"]]
+    for cfg in cfgs:
+        hs = api.HostScene(cfg)
+        osc = oracle.OracleScene(cfg)
+        i = hs.info
+        for cam in (hs.camera(), api.Camera.NotPinhole((0.0, 0.0, 1.0), i["width"], i["height"], (0.0, 0.0, 0.0), 60.0, 0.0, 1.0)):
+            ocol, _, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), threads=8)
+            for opts in ({"onchip": 0, "waves_hbm": 2, "wide": 1}, {"onchip": 0, "waves_hbm": 2}, {"onchip": 0, "waves_hbm": 2, "wide": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12}):
+                sc = api.Scene(hs, options=opts)
+                col, _ = sc.render(cam, i["width"], i["height"], i["spp"], i["max_depth"])
+                fl = sc.flags()
+                assert fl["hbm_kernel"] and fl["simple"] and not fl["onchip"], fl
+                assert_bits_equal(col, ocol, "%s %s" % (os.path.basename(cfg), opts))
