@@ -70,7 +70,7 @@ struct pt_scene {
     int schedMask = 31;          // "sched_mask": scheduling checks every schedMask + 1 bounce iterations (tests use 3)
     bool sliceAlways = true;     // "slice_always" 0: slices only once no fresh tile is left
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // "waves_hbm" 0: scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
-    int nodeKeep = 8, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
+    int nodeKeep = 10, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction

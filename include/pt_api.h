@@ -204,7 +204,7 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
  *   "refill" 0|1|2        resumable traversal: off / scenes in HBM / also LDS-resident scenes (1)
  *   "spec" 1|2            -DPT_SPEC=1 builds only (A/B): speculative descent for closest-hit rays / shadow rays too (2)
- *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (4, 8, 8)
+ *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (4, 10, 8)
  *   "defer_shadow" 0|1    trace shadow + extension ray as a pair in the 4-wave kernel (0)
  *   "slice_iters" n       bounce iterations a wave keeps a tile before it queues it again, 0 = until finished (512)
  *   "slice_always" 0|1    time slices from the first tile on (1)
