@@ -15,7 +15,7 @@ a = ap.parse_args()
 res = {n: [] for n in a.names}
 for r in range(a.rounds):
     for n in a.names:
-        base, _, opt = n.partition("+")              # "v3+defer" = lib_v3.so with PT_DEFER_SHADOW=1
+        base, _, opt = n.partition("+")              # "v3+defer" = lib_v3.so with --opt defer_shadow=1
         lib = os.path.join(ROOT, "cudapathtracer_amd", "csrc", "variants", "lib_%s.so" % base)
         env = dict(os.environ, PT_LIB_PATH=lib)
         extra = []

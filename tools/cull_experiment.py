@@ -9,7 +9,6 @@ wl, spp = sys.argv[1], int(sys.argv[2])
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 s = getattr(scenes, wl)(tempfile.mkdtemp(), width=1920, height=1080, spp=spp, max_depth=depth)
 hs = api.HostScene(s["config"]); sc = api.Scene(hs)
-os.environ.pop("PT_CULL", None)
 def frame(culled):
     sc.set_culling(culled)
     col, cnt = sc.render(hs.camera(), 1920, 1080, spp, depth, counters=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-wave speed vs. full occupancy: kernel time of 1/N of the tiles (N = 32: about one wave per SIMD)
-against full/N. Run with PT_PERSISTENT=0 so that the waves spread over the CUs as workgroups are dispatched."""
+against full/N. One tile per wave (option persistent=0), so that the waves spread over the CUs as workgroups are dispatched."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from cudapathtracer_amd import api, scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 w, h = 1920, 1080
 s = scenes.cornell(tempfile.mkdtemp(), width=w, height=h, spp=spp, max_depth=8)
-hs = api.HostScene(s["config"]); sc = api.Scene(hs)
+hs = api.HostScene(s["config"]); sc = api.Scene(hs, options={"persistent": 0})
 cam = hs.camera()
 buf = torch.zeros(api.n_tiles(w, h), 64, 4, device="cuda")
 def run(world):
