@@ -89,7 +89,7 @@ def kernel_name(flags, variant):
             return "pt::megakernel_hbm_simple<0>"
         return "pt::megakernel_hbm<0, false, %s, %s, false>" % (_tf(flags["culling"]), _tf(flags["refill"]))
     if flags.get("flat_pair"):
-        return "pt::megakernel_flat2<0>"
+        return "pt::megakernel_flat2<0, %s>" % _tf(flags.get("simple", False))
     if flags.get("simple"):
         return "pt::megakernel<0, false, false, true, false, true, true, 1>"
     return "pt::megakernel<0, false, false, %s, %s, %s, false, 1>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))

@@ -76,6 +76,7 @@ struct pt_scene {
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
+    bool noLeafTris = false;                      // no triangle carries a MAT_LEAF material: a shadow ray is occluded by any hit (order-free)
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 (or 2) on: scenes of at most 128 nodes / triangles (64- or 128-bit masks)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0;
@@ -308,6 +309,12 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
             simple = m.type == PT_MAT_DIFFUSE && !m.hasTexture && !m.hasTransMap && !m.boundary && !m.isSpecular;
         }
         s->simpleOk = simple;
+        bool noLeaf = true;
+        for (int i = 0; i < nT && noLeaf; i++) {
+            const int id = d->triangles[i].materialID;
+            noLeaf = id >= 0 && id < d->n_materials && d->materials[id].type != PT_MAT_LEAF;
+        }
+        s->noLeafTris = noLeaf;
     }
     if (!onDevice) {
         if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
@@ -647,7 +654,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     }
     // the instantiations that have the SIMPLE bounce: FLAT, the production kernel for scenes in HBM and its 4-wave form (small shares)
     P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || simpleHbm) ? 1 : 0;
-    if (P.flat == 1 && P.simple && s->flat2Wanted && integrator == PT_UNIDIRECTIONAL && !count && useMIS) P.flat = 3;   // ... and the pair form of FLAT
+    if (P.flat == 1 && s->noLeafTris && !s->armless && s->flat2Wanted && integrator == PT_UNIDIRECTIONAL && !count && useMIS) P.flat = 3;   // ... and the pair form of FLAT
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
     s->lastLaunchFlat2 = (P.flat == 3) ? 1 : 0;

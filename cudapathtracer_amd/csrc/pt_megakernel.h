@@ -456,15 +456,16 @@ template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
 megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE>(P); }
 
-// FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): SIMPLE scenes of at most 64 nodes / triangles, MIS integrator,
-// DEFER logic step; the wave's "stack" area is the 25 x 64-word scratch of the dealt-out tests.
+// FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): scenes of at most 64 nodes / triangles none of which is a MAT_LEAF
+// (any hit occludes a shadow ray) and all of whose materials have a dispatch arm (the DEFER logic step is exact), MIS
+// integrator; with the SIMPLE bounce where the scene allows. The wave's "stack" area is the 25 x 64-word scratch of the tests.
 constexpr int kStackFlat2 = 25;
-template <int INTEG>
+template <int INTEG, bool SIMPLE>
 __global__ void __launch_bounds__(1024)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
 #endif
-megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, true, 1>(P); }
+megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, SIMPLE, 1>(P); }
 
 // ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace.h: trace_resume_w4).
 template <int INTEG>

@@ -11,8 +11,8 @@ hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, d
 #define PT_LDS_OK(K) do { if (lds > 65536u) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e_ != hipSuccess) return e_; } } while (0)
 #define PT_LAUNCH(I, C, RF, FL) do { PT_LDS_OK((megakernel<I, C, false, true, RF, FL>)); hipLaunchKernelGGL((megakernel<I, C, false, true, RF, FL>), grid, block, lds, stream, P); } while (0)
     if (P.flat == 3 && integrator == 0 && !count) {          // both rays of a lane in one FLAT pass (SIMPLE scenes, MIS)
-        PT_LDS_OK(megakernel_flat2<0>);
-        hipLaunchKernelGGL(megakernel_flat2<0>, grid, block, lds, stream, P);
+        if (P.simple) { PT_LDS_OK((megakernel_flat2<0, true>)); hipLaunchKernelGGL((megakernel_flat2<0, true>), grid, block, lds, stream, P); }
+        else { PT_LDS_OK((megakernel_flat2<0, false>)); hipLaunchKernelGGL((megakernel_flat2<0, false>), grid, block, lds, stream, P); }
         return hipGetLastError();
     }
 #define PT_PICK(I) do { if (P.refill) { if (count) PT_LAUNCH(I, true, true, false); else PT_LAUNCH(I, false, true, false); } \

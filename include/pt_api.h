@@ -198,7 +198,8 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
  *   "wide" 0|1            SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes (0: measured 10-30 % slower)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
- *   "flat2" 0|1           SIMPLE FLAT scenes, MIS integrator: shadow ray and next extension ray in one FLAT pass (1)
+ *   "flat2" 0|1           FLAT scenes (<= 64 triangles, no MAT_LEAF triangle), MIS integrator: shadow ray and next extension
+ *                         ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)

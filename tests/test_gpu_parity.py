@@ -865,3 +865,26 @@ def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
                 fl = sc.flags()
                 assert fl["hbm_kernel"] and fl["simple"] and not fl["onchip"], fl
                 assert_bits_equal(col, ocol, "%s %s" % (os.path.basename(cfg), opts))
+
+
+def test_flat_pair_kernel_generic_bounce(api, oracle, gpu_ready, scene_dir):
+    """The pair form of FLAT needs an order-free shadow ray (no MAT_LEAF triangle in the scene) and an exact DEFER step (every
+    material has a dispatch arm), not the SIMPLE bounce: mirror / glass / nested water / conductors take it with the generic
+    bounce; a scene with leaf materials must not."""
+    from cudapathtracer_amd import scenes
+    for case, pair in (("mixed32_mis", True), ("metal32_mis", True), ("textured32_mis", False)):
+        g = np.load(os.path.join(GOLDEN, case + ".npz"))
+        hs = api.HostScene(golden_case_scene(g))
+        for opts in ({}, {"flat2": 0}, {"slice_iters": 8, "sched_mask": 3}):
+            sc = api.Scene(hs, options=opts)
+            col, _ = sc.render(hs.camera(), int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]))
+            fl = sc.flags()
+            assert fl["flat"] and not fl["simple"] and fl["flat_pair"] == (pair and opts.get("flat2", 1) == 1), (case, opts, fl)
+            assert_bits_equal(col, g["colors"], "%s %s" % (case, opts))
+    cfg = scenes.cornell(os.path.join(scene_dir, "pgmix"), 48, 32, 6, 12, tall_material=19, short_material=18, nested=True, doubled=4, name="pgmix")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    i = hs.info
+    ocol, _, _ = osc.render(threads=8)
+    col, _ = gs.render(hs.camera(), i["width"], i["height"], i["spp"], i["max_depth"])
+    assert gs.flags()["flat_pair"] and not gs.flags()["simple"], gs.flags()
+    assert_bits_equal(col, ocol, "mirror + diamond + nested water + doubled gold box, pair form")
