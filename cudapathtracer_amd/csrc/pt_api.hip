@@ -55,7 +55,8 @@ struct DevBuf {
 
 struct pt_scene {
     int device = 0;
-    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves, wnodes;
+    DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves, wnodes, qnodes, leafBox, mids;
+    bool compactTried = false, compactOk = false, compactWanted = false; QFrame qframe{};   // 32-byte quantised nodes of trace_resume_q ("compact" 1)
     int nWide = 0, wideStackNeed = 0; bool wideTried = false, wideWanted = false;   // the 4-wide collapsed tree of trace_resume_w4 ("wide" 1: opt-in, measured slower)
     int nLeaves = 0;                                  // FLAT scenes: the leaf table (pt_trace.h: visited(leaf) == slab(leaf's own box))
     DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
@@ -127,7 +128,7 @@ int pt_device_count(void) {
 
 void pt_scene_destroy(pt_scene* s) {
     if (!s) return;
-    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals, &s->leaves, &s->wnodes,
+    DevBuf* all[] = {&s->nodes, &s->tris, &s->attrs, &s->lights, &s->mats, &s->textures, &s->jump, &s->totals, &s->leaves, &s->wnodes, &s->qnodes, &s->leafBox, &s->mids,
                      &s->rng, &s->spill, &s->tilebuf, &s->colors, &s->pixcnt, &s->queue, &s->left, &s->wfState, &s->wfCtl, &s->wfCtr, &s->wfSpill};
     for (DevBuf* b : all) b->release();
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -591,6 +592,89 @@ static int ensure_wide(pt_scene* s) {
     return 0;
 }
 
+// The compact form of the tree for trace_resume_q (pt_trace.h), built once per scene from the packed binary records: per
+// internal node a QNode (both child boxes in 16-bit fixed point in one frame for the whole scene, rounded OUTWARD with
+// the very fmaf the kernel decodes with), per leaf its exact float box (at the index of its first packed triangle) and per
+// internal node the first triangle of its right subtree (the tie rule's walk).
+static int ensure_compact(pt_scene* s) {
+    if (s->compactTried) return 0;
+    s->compactTried = true;
+    const int nI = s->nInternal, nT = s->nTrisPacked;
+    if (nI <= 0 || s->ds.rootRef != 0) return 0;
+    std::vector<PNode> pn((size_t)nI);
+    HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nI * sizeof(PNode), hipMemcpyDeviceToHost));
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = std::min(pn[0].lmin[a], pn[0].rmin[a]); hi[a] = std::max(pn[0].lmax[a], pn[0].rmax[a]); }
+    for (int i = 0; i < nI; i++)                                   // (nested boxes make the root's the extent; do not rely on it)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], std::min(pn[i].lmin[a], pn[i].rmin[a])); hi[a] = std::max(hi[a], std::max(pn[i].lmax[a], pn[i].rmax[a]));
+            if (!std::isfinite(pn[i].lmin[a]) || !std::isfinite(pn[i].lmax[a]) || !std::isfinite(pn[i].rmin[a]) || !std::isfinite(pn[i].rmax[a])) return 0;
+        }
+    float org[3], scl[3];
+    for (int a = 0; a < 3; a++) {
+        org[a] = lo[a];
+        float sc = (hi[a] - lo[a]) / 65535.0f;
+        if (!(sc > 0.0f)) sc = 1e-30f;
+        for (int k = 0; k < 64 && std::fmaf(65535.0f, sc, org[a]) < hi[a]; k++) sc = std::nextafter(sc, INFINITY);
+        if (std::fmaf(65535.0f, sc, org[a]) < hi[a] || !std::isfinite(sc)) return 0;
+        scl[a] = sc;
+    }
+    auto down = [&](float x, int a) {                              // largest q with decode(q) <= x
+        int q = (int)std::floor(((double)x - org[a]) / scl[a]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q > 0 && std::fmaf((float)q, scl[a], org[a]) > x) q--;
+        return (uint16_t)q;
+    };
+    auto up = [&](float x, int a) {                                // smallest q with decode(q) >= x
+        int q = (int)std::ceil(((double)x - org[a]) / scl[a]);
+        q = std::min(std::max(q, 0), 65535);
+        while (q < 65535 && std::fmaf((float)q, scl[a], org[a]) < x) q++;
+        return (uint16_t)q;
+    };
+    std::vector<QNode> qn((size_t)nI);
+    std::vector<float> lb((size_t)nT * 8, 0.0f);                   // two 16-byte halves per packed triangle index; filled at the first of each leaf
+    std::vector<int32_t> mids((size_t)nI, 0), minFirst((size_t)nI, 0), maxFirst((size_t)nI, 0);
+    bool ok = true;
+    for (int i = nI - 1; i >= 0 && ok; i--) {                      // children come after their parent (breadth-first numbering): bottom-up
+        const PNode& p = pn[i];
+        QNode& q = qn[i];
+        for (int a = 0; a < 3; a++) { q.lmin[a] = down(p.lmin[a], a); q.lmax[a] = up(p.lmax[a], a); q.rmin[a] = down(p.rmin[a], a); q.rmax[a] = up(p.rmax[a], a); }
+        q.left = p.left; q.right = p.right;
+        int mn[2], mx[2];
+        const int32_t ref[2] = {p.left, p.right};
+        for (int k = 0; k < 2 && ok; k++) {
+            if (ref[k] >= 0) { ok = ref[k] > i && ref[k] < nI; if (ok) { mn[k] = minFirst[ref[k]]; mx[k] = maxFirst[ref[k]]; } }
+            else {
+                const int f = ~ref[k];
+                ok = ref[k] != kRefNone && f >= 0 && f < nT;
+                if (!ok) break;
+                mn[k] = mx[k] = f;
+                const float* bmn = k == 0 ? p.lmin : p.rmin; const float* bmx = k == 0 ? p.lmax : p.rmax;
+                float* o = &lb[(size_t)f * 8];
+                o[0] = bmn[0]; o[1] = bmn[1]; o[2] = bmn[2]; o[3] = bmx[0]; o[4] = bmx[1]; o[5] = bmx[2];
+            }
+        }
+        if (!ok) break;
+        ok = mx[0] < mn[1];                                        // leaf order is left to right
+        minFirst[i] = mn[0]; maxFirst[i] = mx[1]; mids[i] = mn[1];
+    }
+    if (!ok) return 0;
+    for (int i = 0; i < nI && ok; i++) {                           // every decoded box contains the float box
+        const PNode& p = pn[i]; const QNode& q = qn[i];
+        for (int a = 0; a < 3; a++) {
+            auto dec = [&](uint16_t v) { return std::fmaf((float)v, scl[a], org[a]); };
+            ok = ok && dec(q.lmin[a]) <= p.lmin[a] && dec(q.lmax[a]) >= p.lmax[a] && dec(q.rmin[a]) <= p.rmin[a] && dec(q.rmax[a]) >= p.rmax[a];
+        }
+    }
+    if (!ok) return 0;
+    if (int r = upload(s->qnodes, qn.data(), qn.size() * sizeof(QNode))) return r;
+    if (int r = upload(s->leafBox, lb.data(), lb.size() * sizeof(float))) return r;
+    if (int r = upload(s->mids, mids.data(), mids.size() * sizeof(int32_t))) return r;
+    s->qframe = QFrame{org[0], org[1], org[2], scl[0], scl[1], scl[2]};
+    s->compactOk = true;
+    return 0;
+}
+
 // rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
 static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
                         uint64_t seed, const TileSpan& t, void* d_tiles, uint32_t* d_pixcnt, bool count, hipStream_t stream, bool continueStreams) {
@@ -617,6 +701,11 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         if (int r = ensure_wide(s)) return r;
         wide = s->nWide > 0;
     }
+    bool compact = false;
+    if (hbm && simpleHbm && s->compactWanted && !wide) {
+        if (int r = ensure_compact(s)) return r;
+        compact = s->compactOk;
+    }
     const int spillEntries = hbm ? std::max(0, (wide ? std::max(s->wideStackNeed, s->stackNeed) : s->stackNeed) - kStackLdsHbm) : s->ds.stackSpill;
     const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
@@ -641,6 +730,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
     P.wide = wide ? 1 : 0; P.wnodes = wide ? (const WNode*)s->wnodes.p : nullptr;
     if (wide) P.cacheNodes = 2 * std::min(s->nWide, kCacheBytesHbmSimple / 128);            // wide nodes, counted in 64-byte halves
+    P.compact = compact ? 1 : 0;
+    P.qnodes = compact ? (const QNode*)s->qnodes.p : nullptr; P.leafBox = compact ? s->leafBox.p : nullptr; P.mids = compact ? (const int32_t*)s->mids.p : nullptr;
+    P.qframe = s->qframe;
+    if (compact) P.cacheNodes = std::min(s->nInternal & ~1, kCacheBytesHbmSimple / 32) / 2;     // compact nodes, two per 64-byte unit
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
@@ -844,6 +937,7 @@ const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
     {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1}, {"wide", 0, 1},
+    {"compact", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -878,6 +972,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 17: s->flat2Wanted = v; break;
         case 18: s->leafBoxes = v != 0; break;
         case 19: s->wideWanted = v != 0; break;
+        case 20: s->compactWanted = v != 0; break;
     }
     return 0;
 }
@@ -905,6 +1000,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 17: *out = s->flat2Wanted; break;
         case 18: *out = s->leafBoxes; break;
         case 19: *out = s->wideWanted; break;
+        case 20: *out = s->compactWanted; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

@@ -173,6 +173,16 @@ struct __attribute__((aligned(128))) WNode {
 };
 static_assert(sizeof(WNode) == 128, "WNode");
 
+// Compact internal node for the SIMPLE kernel for scenes in HBM (pt_trace.h: trace_resume_q): both children's boxes as 16-bit
+// fixed point in ONE frame for the whole scene (x = fma(q, scale, origin)), rounded OUTWARD so that each decoded box contains
+// the reference's float box; refs as in PNode. Half a PNode: two 16-byte loads per visit instead of four.
+struct __attribute__((aligned(16))) QNode {
+    uint16_t lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+};
+static_assert(sizeof(QNode) == 32, "QNode");
+struct QFrame { float ox, oy, oz, sx, sy, sz; };
+
 // FLAT kernels: one record per LEAF of the tree — the leaf's own box (as stored with its parent) and its triangle range.
 struct __attribute__((aligned(16))) PLeaf {
     float mn[3], mx[3];

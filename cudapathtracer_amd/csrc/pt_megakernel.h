@@ -141,7 +141,7 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, bool WIDE = false>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, int TREE = 0>
 PT_DEV void megakernel_body(const KParams& P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
@@ -151,7 +151,9 @@ PT_DEV void megakernel_body(const KParams& P) {
     constexpr int kMedBytes = SIMPLE ? 0 : kMediumMax * 64;                 // SIMPLE kernels have no medium stack (pt_path.h)
     const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMedBytes) : 0;
     DeviceScene Sstage = S;
+    constexpr bool WIDE = TREE == 1, COMPACT = TREE == 2;
     if (WIDE) Sstage.nodes = reinterpret_cast<const PNode*>(P.wnodes);       // the LDS scene cache of the WIDE kernel holds wide nodes (P.cacheNodes counts 64-byte halves)
+    if (COMPACT) Sstage.nodes = reinterpret_cast<const PNode*>(P.qnodes);    // ... of the COMPACT kernel 32-byte nodes, two per unit
     const SceneCache SC = stage_scene_cache(Sstage, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights, P.leaves, P.cacheLeaves);      // contains the only barrier
     lds_cf4* leafTable = (lds_cf4*)(pt_smem + attrOff + P.cacheAttrs * 80 + P.cacheMats * 96 + P.cacheLights * 64);      // FLAT kernels (attrOff > 0 there)
     if constexpr (ATTRLDS) {
@@ -329,6 +331,12 @@ PT_DEV void megakernel_body(const KParams& P) {
             PT_STAMP(2);
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
+            if constexpr (COMPACT) {
+                const Compact K{P.qnodes, reinterpret_cast<const f4v*>(P.leafBox), P.mids, P.qframe};
+                trace_resume_q<STACKN>(S, SC, K, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, Keep{P.nodeKeep, P.triKeep});
+                PT_STAMP(1);
+                continue;
+            }
             if constexpr (WIDE) {
                 trace_resume_w4<STACKN>(S, SC, P.wnodes, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
                 if (!(rs.flags & kRayBusy) && (rs.flags & kRayTie)) {
@@ -470,7 +478,12 @@ megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFl
 // ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace.h: trace_resume_w4).
 template <int INTEG>
 __global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
-megakernel_hbm_wide(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, true>(P); }
+megakernel_hbm_wide(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, 1>(P); }
+
+// ... and on 32-byte quantised nodes with exact leaf boxes (pt_trace.h: trace_resume_q).
+template <int INTEG>
+__global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
+megakernel_hbm_compact(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, 2>(P); }
 
 // The SIMPLE production kernel for scenes in HBM: 8 waves per SIMD, 16-wave workgroups (pt_params.h).
 template <int INTEG>

@@ -14,6 +14,8 @@ hipError_t launch_megakernel_hbm(int integrator, bool count, bool syncShadow, bo
 #define PT_LAUNCH_HBM(I, C) do { if (P.cull) PT_LAUNCH_HBM1(I, C, true, false); \
                                  else if (P.refill && P.simple && P.wide && !C) { PT_LDS_OK((megakernel_hbm_wide<I>)); \
                                                                                   hipLaunchKernelGGL((megakernel_hbm_wide<I>), grid, block, lds, stream, P); } \
+                                 else if (P.refill && P.simple && P.compact && !C) { PT_LDS_OK((megakernel_hbm_compact<I>)); \
+                                                                                     hipLaunchKernelGGL((megakernel_hbm_compact<I>), grid, block, lds, stream, P); } \
                                  else if (P.refill && P.simple && !C) { PT_LDS_OK((megakernel_hbm_simple<I>)); \
                                                                         hipLaunchKernelGGL((megakernel_hbm_simple<I>), grid, block, lds, stream, P); } \
                                  else if (P.refill) PT_LAUNCH_HBM1(I, C, false, true); \

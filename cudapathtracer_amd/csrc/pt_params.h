@@ -63,6 +63,8 @@ struct KParams {
     int cacheAttrs, cacheMats, cacheLights;   // ONCHIP kernels: PAttr / PMat / PLight records staged behind the stacks (all or none; 0 = read from global memory)
     int wide;                      // 1: megakernel_hbm_wide — the SIMPLE kernel for scenes in HBM on the 4-wide collapsed tree `wnodes`
     const WNode* wnodes;
+    int compact;                   // 1: megakernel_hbm_compact — the SIMPLE kernel for scenes in HBM on 32-byte quantised nodes (pt_trace.h: trace_resume_q)
+    const QNode* qnodes; const void* leafBox; const int32_t* mids; QFrame qframe;
     int cacheLeaves;               // FLAT kernels: PLeaf records staged behind them (0 = none: the lockstep node walk)
     const PLeaf* leaves;
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation

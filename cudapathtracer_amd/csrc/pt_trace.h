@@ -965,7 +965,7 @@ struct RayState {
     int32_t pend;                      // trace_resume_spec: the one postponed leaf (kRefNone = none)
     uint32_t flags;                    // kRayBusy | kRayShadow | kRayExtFollows
 };
-constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u;
+constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u, kRayInLeaf = 32u;
 
 template <bool COUNT, int N>
 PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasShadow, V3 so, V3 sd, float smaxt,
@@ -1167,6 +1167,146 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
     r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur; r.pend = pend;
     r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
+}
+
+// ---- compact nodes (SIMPLE scenes in HBM) --------------------------------------------------------
+// visited(leaf) == slab(leaf's own box) for a ray with a regular 1 / d (see inv_is_regular): the boxes ABOVE the leaves only
+// have to contain them. So the inner nodes can be stored smaller than the reference stores them — QNode: 16-bit fixed
+// point, rounded outward, 32 bytes, two 16-byte loads per visit instead of four, twice as many nodes per cache line and in
+// the LDS copy of the top of the tree — as long as a leaf is entered only if its EXACT box passes (leafBox, 2 loads per
+// candidate leaf) and the result is the reference's: minimum t, and where two triangles return the same t the one the
+// reference visits first — decided, when it happens, by walking the reference's own nodes (exact boxes, PNode.pad0 = first
+// triangle of the right subtree) down to where the two leaves part and asking which child the reference enters first
+// (`tL < tR`, else the right one). Lanes whose ray has a zero direction component (`exact`) fetch the reference's PNodes
+// instead, in the same loop. Shadow rays of a NOLEAF scene are occluded by any hit.
+// MEASURED (profiles/r02_ab_compact.log): bit-identical frames, and SLOWER — 82 k triangles 214 -> 260 ms (32 spp), 263 k
+// triangles 199 -> 240 ms (8 spp). Cache-line accesses per ray fall by a third, wave-level VALU instructions rise by a fifth
+// (unpack + convert + fma per plane), and the time follows the instructions: the kernel for scenes in HBM is not bound by
+// its L1 line rate alone. Loading a leaf's first triangle together with its box (one latency step instead of
+// two) is another 3 % slower. Not the default: option "compact" = 1 to reproduce.
+struct Compact { const QNode* q; const f4v* leafBox; const int32_t* mids; QFrame f; };
+
+PT_DEV bool tie_keeps_first(const DeviceScene& S, const int32_t* __restrict__ mids, V3 o, V3 inv, int tiBest, int tiNew) {
+    // both triangles returned the same t: true if the reference visits tiBest's before tiNew's (packed indices, leaf order)
+    int32_t ref = S.rootRef;
+    while (ref >= 0) {
+        const f4v* p = reinterpret_cast<const f4v*>(S.nodes + ref);
+        NodeData n; n.a = p[0]; n.b = p[1]; n.c = p[2]; n.d = p[3];
+        const int mid = mids[ref];
+        const bool bestLeft = tiBest < mid, newLeft = tiNew < mid;
+        if (bestLeft != newLeft) {
+            float tL, tR;
+            slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
+            slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);
+            return (tL < tR) == bestLeft;                          // the reference enters the left child first iff tL < tR
+        }
+        ref = bestLeft ? f2i(n.d.x) : f2i(n.d.y);
+    }
+    return tiBest < tiNew;                                         // same leaf: ascending order inside it
+}
+
+template <int N>
+PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Compact& K, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy, V3& thr, Hit& h, Keep k) {
+    if (!(r.flags & kRayBusy)) return;
+    const QNode* __restrict__ Q = K.q;
+    const f4v* __restrict__ leafBox = K.leafBox;
+    const QFrame F = K.f;
+    int bestTi = r.pend;                                           // the packed index of the best hit so far (for the tie rule)
+    bool inLeaf = (r.flags & kRayInLeaf) != 0;                     // `cur` resumes a leaf whose own box has been tested
+    V3 o = r.o, d = r.d, inv = r.inv;
+    float max_t = r.max_t, min_t = r.min_t;
+    int32_t cur = r.cur;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    bool exact = !inv_is_regular(inv);
+    const int nLdsQ = C.nNodes << 1;                               // the LDS scene cache holds the first nLdsQ compact nodes (2 per 64 bytes)
+    while (true) {
+        const int active = lanes_here();
+        if (active <= minBusy) break;
+        const int keepN = (active * k.node) >> 4;
+        while (cur >= 0) {
+            float b[12];                                           // left min xyz, left max xyz, right min xyz, right max xyz
+            int32_t left, right;
+            if (exact) {
+                const f4v* p = reinterpret_cast<const f4v*>(S.nodes + cur);
+                const f4v a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+                b[0] = a0.x; b[1] = a0.y; b[2] = a0.z; b[3] = a0.w; b[4] = a1.x; b[5] = a1.y;
+                b[6] = a1.z; b[7] = a1.w; b[8] = a2.x; b[9] = a2.y; b[10] = a2.z; b[11] = a2.w;
+                left = f2i(a3.x); right = f2i(a3.y);
+            } else {
+                f4v q0, q1;
+                if (cur < nLdsQ) { lds_cf4* p = C.nodes + cur * 2; q0 = p[0]; q1 = p[1]; }
+                else { const f4v* p = reinterpret_cast<const f4v*>(Q + cur); q0 = p[0]; q1 = p[1]; }
+                const uint32_t w0 = f2u(q0.x), w1 = f2u(q0.y), w2 = f2u(q0.z), w3 = f2u(q0.w), w4 = f2u(q1.x), w5 = f2u(q1.y);
+                b[0] = __builtin_fmaf((float)(w0 & 0xffffu), F.sx, F.ox); b[1] = __builtin_fmaf((float)(w0 >> 16), F.sy, F.oy); b[2] = __builtin_fmaf((float)(w1 & 0xffffu), F.sz, F.oz);
+                b[3] = __builtin_fmaf((float)(w1 >> 16), F.sx, F.ox); b[4] = __builtin_fmaf((float)(w2 & 0xffffu), F.sy, F.oy); b[5] = __builtin_fmaf((float)(w2 >> 16), F.sz, F.oz);
+                b[6] = __builtin_fmaf((float)(w3 & 0xffffu), F.sx, F.ox); b[7] = __builtin_fmaf((float)(w3 >> 16), F.sy, F.oy); b[8] = __builtin_fmaf((float)(w4 & 0xffffu), F.sz, F.oz);
+                b[9] = __builtin_fmaf((float)(w4 >> 16), F.sx, F.ox); b[10] = __builtin_fmaf((float)(w5 & 0xffffu), F.sy, F.oy); b[11] = __builtin_fmaf((float)(w5 >> 16), F.sz, F.oz);
+                left = f2i(q1.z); right = f2i(q1.w);
+            }
+            float tL, tR;
+            const bool hL = slab(b[0], b[1], b[2], b[3], b[4], b[5], o, inv, tL);
+            const bool hR = slab(b[6], b[7], b[8], b[9], b[10], b[11], o, inv, tR);
+            if (hL && hR) {
+                const bool leftNear = tL < tR;
+                st.push(leftNear ? right : left);
+                cur = leftNear ? left : right;
+            } else if (hL) cur = left;
+            else if (hR) cur = right;
+            else cur = st.sp > 0 ? st.pop() : kRefNone;
+            if (lanes_here() <= keepN) break;
+        }
+        if (cur >= 0) continue;
+        if (cur == kRefNone) {
+            if (isShadow && extFollows) {                           // shadow ray done: start this lane's extension ray
+                isShadow = false; extFollows = false;
+                o = eo; d = ed; inv = inv3(d); max_t = 999999.0f;
+                exact = !inv_is_regular(inv);
+                cur = S.rootRef; st.sp = 0;
+                continue;
+            }
+            busy = false;
+            break;
+        }
+        int32_t ti = ~cur;
+        bool enter = true;
+        if (!exact && !inLeaf) {                                    // the leaf's own box, exactly
+            const f4v l0 = leafBox[2 * ti], l1 = leafBox[2 * ti + 1];
+            float t0;
+            enter = slab(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, o, inv, t0);
+        }
+        inLeaf = false;
+        uint32_t idx;
+        bool occluded = false, more = false;
+        if (enter) {
+            const int keepT = (lanes_here() * k.tri) >> 4;
+            do {
+                TriData q = load_tri<false>(S, C, ti);
+                idx = f2u(q.e.y);
+                float t, u, v;
+                bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+                if (isShadow) {
+                    if (ok && (t < max_t)) { thr = v3(0.0f); occluded = true; break; }       // NOLEAF scene: any hit ends the ray
+                } else if (ok && (t < max_t)) {
+                    bool take = t < min_t;
+                    if (!take && t == min_t && h.tri >= 0) take = !tie_keeps_first(S, K.mids, o, inv, bestTi, ti);
+                    if (take) {
+                        min_t = t; bestTi = ti;
+                        h.t = t; h.u = u; h.v = v;
+                        h.tri = (int32_t)(idx & 0x7fffffffu);
+                        h.material = f2i(q.e.z);
+                    }
+                }
+                ti++;
+                more = !(idx & 0x80000000u);
+                if (more && lanes_here() <= keepT) break;
+            } while (more);
+        }
+        if (!occluded && more) { cur = ~ti; inLeaf = true; continue; }   // the rest of this leaf next time round
+        cur = (!occluded && st.sp > 0) ? st.pop() : kRefNone;
+        if (occluded) st.sp = 0;
+    }
+    r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur; r.pend = bestTi;
+    r.flags = (inLeaf ? kRayInLeaf : 0u) | (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
 }
 
 // ---- wide traversal (SIMPLE scenes in HBM) --------------------------------------------------------

@@ -197,6 +197,7 @@ int pt_set_culling(pt_scene* scene, int on);
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
  *   "wide" 0|1            SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes (0: measured 10-30 % slower)
+ *   "compact" 0|1         ... or 32-byte quantised inner nodes with exact leaf boxes (0: same frames, measured 20 % slower)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
  *   "flat2" 0|1           FLAT scenes (<= 64 triangles, no MAT_LEAF triangle), MIS integrator: shadow ray and next extension
  *                         ray in one FLAT pass (1)

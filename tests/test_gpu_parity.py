@@ -635,7 +635,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 10, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -663,7 +663,7 @@ def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
     return col[y0:y1, x0:x1], (cnt[y0:y1, x0:x1] if counters else None)
 
 
-@pytest.mark.parametrize("mode", ["production", "generic_bounce", "plain_loops_4wave", "counted", "wavefront"])
+@pytest.mark.parametrize("mode", ["production", "generic_bounce", "plain_loops_4wave", "counted", "wavefront", "compact"])
 @pytest.mark.parametrize("case", window_cases())
 def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, mode):
     """BASELINE C3 / C4 / C5 geometry and depth at the 1080p camera, against the oracle: 64x64 windows of the 82 k-triangle
@@ -677,7 +677,7 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
     hs = api.HostScene(s["config"])
     w, h, spp, md = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"])
     opts = {"production": {"waves_hbm": 2}, "generic_bounce": {"waves_hbm": 2, "simple": 0}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
-            "counted": {"waves_hbm": 2}, "wavefront": {}}[mode]
+            "counted": {"waves_hbm": 2}, "wavefront": {}, "compact": {"waves_hbm": 2, "compact": 1}}[mode]
     sc = api.Scene(hs, options=opts)
     if mode == "wavefront":
         sc.set_variant("wavefront")
@@ -687,10 +687,10 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
         assert_bits_equal(col, g["colors"][k], "%s window %d (%s)" % (case, k, mode))
         if mode == "counted":
             assert np.array_equal(cnt, g["counters"][k]), (case, k)
-        if mode in ("production", "generic_bounce"):
+        if mode in ("production", "generic_bounce", "compact"):
             fl = sc.flags()
             assert fl["hbm_kernel"] and fl["refill"] and not fl["onchip"] and not fl["culling"], fl
-            assert fl["simple"] == (mode == "production"), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
+            assert fl["simple"] == (mode != "generic_bounce"), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
     x0, y0, x1, y1 = (int(v) for v in g["rects"][1])
     ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8)
     assert_bits_equal(ocol[y0:y1, x0:x1], g["colors"][1], "fixture == live oracle")
@@ -849,7 +849,9 @@ def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
     """pt_trace.h trace_resume_w4: SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes, children in no
     particular order; equal-t ties and rays with a zero direction component fall back to the reference traversal. A scene
     whose every second quad is DOUBLED (each hit on them a two-way tie between different leaves), an axis-aligned camera
-    (primary rays with exact zero components), and a blob — against the oracle. Opt-in ("wide" = 1): measured slower."""
+    (primary rays with exact zero components), and a blob — against the oracle. Opt-in ("wide" = 1): measured slower.
+    The same cases for trace_resume_q ("compact" = 1: quantised inner nodes, exact leaf boxes, ties decided by a walk down
+    the reference's nodes; rays with a zero direction component read the reference's nodes in the same loop)."""
     from cudapathtracer_amd import scenes
     cfgs = [scenes.blob_in_box(os.path.join(scene_dir, "wblob4"), 64, 40, 3, 8, subdiv=4, name="wblob4")["config"],
             scenes.cornell(os.path.join(scene_dir, "wtwin"), 48, 32, 4, 10, doubled=17, extra_boxes=7, ceiling_light=True, name="wtwin")["config"]]
@@ -859,7 +861,8 @@ def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
         i = hs.info
         for cam in (hs.camera(), api.Camera.NotPinhole((0.0, 0.0, 1.0), i["width"], i["height"], (0.0, 0.0, 0.0), 60.0, 0.0, 1.0)):
             ocol, _, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), threads=8)
-            for opts in ({"onchip": 0, "waves_hbm": 2, "wide": 1}, {"onchip": 0, "waves_hbm": 2}, {"onchip": 0, "waves_hbm": 2, "wide": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12}):
+            for opts in ({"onchip": 0, "waves_hbm": 2, "wide": 1}, {"onchip": 0, "waves_hbm": 2}, {"onchip": 0, "waves_hbm": 2, "wide": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12},
+                         {"onchip": 0, "waves_hbm": 2, "compact": 1}, {"onchip": 0, "waves_hbm": 2, "compact": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12}):
                 sc = api.Scene(hs, options=opts)
                 col, _ = sc.render(cam, i["width"], i["height"], i["spp"], i["max_depth"])
                 fl = sc.flags()
