@@ -375,7 +375,13 @@ PT_DEV void megakernel_body(const KParams& P) {
         const bool hasShadow = DEFER && (ps.flags & kShadowPending) != 0;
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
-        if constexpr (DEFER && FLAT) trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c, P.cacheNodes, leafTable, P.cacheLeaves);
+        if constexpr (DEFER && FLAT) {
+            trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c, P.cacheNodes, leafTable, P.cacheLeaves);
+#ifdef PT_DIAG_DOUBLE_PAIR          // cost measurement only: the pair pass run twice, same result
+            { Hit h2; V3 thr2; trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr2, h2, c, P.cacheNodes, leafTable, P.cacheLeaves);
+              if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); thr.x = fminf_(thr.x, thr2.x); }
+#endif
+        }
         else if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
         else if constexpr (FLAT) {
             trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes, leafTable, P.cacheLeaves);

@@ -21,6 +21,8 @@ for r in range(a.rounds):
         extra = []
         if opt == "defer":
             extra = ["--opt", "defer_shadow=1"]
+        elif "=" in opt:                             # "base+compact=1": any pt_set_option
+            extra = ["--opt", opt]
         if a.golden and r == 0:
             t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k", "golden or fresh or deep"], cwd=ROOT, env=env, capture_output=True, text=True)
             print(n, "parity:", t.stdout.strip().splitlines()[-1] if t.stdout.strip() else t.stderr[-300:], flush=True)
