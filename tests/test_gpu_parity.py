@@ -480,6 +480,27 @@ def test_edge_frames(api, oracle, gpu_ready, scene_dir, shape):
         assert_bits_equal(timed, ocol, "edge frame %s integrator %d, timed kernel" % (shape, integ))
 
 
+def test_scene_without_lights_and_camera_that_sees_nothing(api, oracle, gpu_ready, scene_dir):
+    """nextEventEstimation with lightNum == 0 draws nothing and adds nothing (deviceCode.cu:87-156), and every ray of a camera
+    that looks away from the scene misses: black frames, but the RNG streams, the counters and the kernels' bookkeeping
+    (pair pass with no shadow ray at all, waves whose paths all end at once) must still be the reference's."""
+    from cudapathtracer_amd import scenes
+    cfg = scenes.cornell(os.path.join(scene_dir, "dark"), 40, 24, 3, 6, light_mult=0.0, name="dark")["config"]
+    gs, hs, osc = _scene_pair(api, oracle, cfg)
+    i = hs.info
+    assert i["n_lights"] == 0
+    away = api.Camera.NotPinhole((0.0, 0.0, 1.0), i["width"], i["height"], (0.0, 180.0, 0.0), 60.0, 0.0, 1.0)
+    for cam in (hs.camera(), away):
+        for integ in (0, 2):
+            ocol, ocnt, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), integrator=integ, counters=True)
+            col, cnt = gs.render(cam, i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ, counters=True)
+            assert np.array_equal(cnt, ocnt), integ
+            assert_bits_equal(col, ocol, "dark scene, integrator %d" % integ)
+            timed, _ = gs.render(cam, i["width"], i["height"], i["spp"], i["max_depth"], integrator=integ)
+            assert_bits_equal(timed, ocol, "dark scene, integrator %d, timed kernel" % integ)
+            assert not np.any(ocol[..., :3]) and not np.any(ocnt[..., 1])      # black, and not one shadow ray
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_scenes(api, oracle, gpu_ready, scene_dir, seed):
     """Seeded random scenes (scenes.fuzz): random materials from the whole table on walls and objects, nested and
