@@ -105,7 +105,7 @@ static int queue_error(pt_scene* s);
 // size (in waves) that holds the scene, 0 if none does.
 static int scene_onchip_wg(const pt_scene* s) {
     if (!s->onchipOk || s->nTrisPacked <= 0 || s->ds.stackSpill != 0) return 0;
-    const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked, s->nTrisPacked <= 128 ? s->nTrisPacked : 0);   // (+ room for the FLAT kernels' leaf table: at most one leaf per triangle)
+    const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked);
     for (int wg = 4; wg <= 16; wg *= 2)
         if (geom <= (size_t)kCacheBytes * (wg / 4) && (kAttrCacheBytes == 0 || rec <= (size_t)kAttrCacheBytes * (wg / 4))) return wg;
     return 0;
@@ -723,9 +723,9 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.cacheNodes = s->cacheNodes; P.cacheTris = s->cacheTris;
     if (onchip) { P.cacheNodes = s->nInternal; P.cacheTris = s->nTrisPacked; }      // the whole scene, in workgroups large enough to hold it
     P.cacheAttrs = P.cacheMats = P.cacheLights = 0;
-    P.cacheLeaves = 0; P.leaves = nullptr;
+    P.nLeaves = 0; P.leaves = nullptr;
     if (onchip && kAttrCacheBytes > 0) { P.cacheAttrs = s->nTrisPacked; P.cacheMats = s->nMats; P.cacheLights = s->nLightsPacked; }   // the bounce's records in LDS as well
-    if (onchip && kAttrCacheBytes > 0 && s->flatOk && s->leafBoxes && s->nLeaves > 0) { P.cacheLeaves = s->nLeaves; P.leaves = (const PLeaf*)s->leaves.p; }
+    if (onchip && kAttrCacheBytes > 0 && s->flatOk && s->leafBoxes && s->nLeaves > 0) { P.nLeaves = s->nLeaves; P.leaves = (const PLeaf*)s->leaves.p; }
     P.wgWaves = wgWaves;
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
     P.wide = wide ? 1 : 0; P.wnodes = wide ? (const WNode*)s->wnodes.p : nullptr;

@@ -25,8 +25,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pt_smem[];
 
 // All threads of the workgroup copy the cached part of the scene into LDS (16 B per thread per step). attrOff > 0
 // (LDS-resident scenes): the records the bounce reads — nA PAttr, nM PMat, nL PLight — go to byte offset attrOff too.
-PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int cacheTris, int attrOff = 0, int nA = 0, int nM = 0, int nL = 0,
-                                    const PLeaf* leaves = nullptr, int nLeaves = 0) {
+PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int cacheTris, int attrOff = 0, int nA = 0, int nM = 0, int nL = 0) {
     typedef __attribute__((address_space(3))) f4v lds_f4;
     lds_f4* dstN = (lds_f4*)pt_smem;
     lds_f4* dstT = dstN + cacheNodes * 4;
@@ -44,9 +43,6 @@ PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int ca
         for (int i = threadIdx.x; i < nA * 5; i += blockDim.x) dA[i] = sA[i];
         for (int i = threadIdx.x; i < nM * 6; i += blockDim.x) dM[i] = sM[i];
         for (int i = threadIdx.x; i < nL * 4; i += blockDim.x) dL[i] = sL[i];
-        lds_f4* dF = dL + nL * 4;                                   // the FLAT kernels' leaf table
-        const f4v* sF = reinterpret_cast<const f4v*>(leaves);
-        for (int i = threadIdx.x; i < nLeaves * 2; i += blockDim.x) dF[i] = sF[i];
     }
     __syncthreads();
     SceneCache C;
@@ -154,8 +150,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     constexpr bool WIDE = TREE == 1, COMPACT = TREE == 2;
     if (WIDE) Sstage.nodes = reinterpret_cast<const PNode*>(P.wnodes);       // the LDS scene cache of the WIDE kernel holds wide nodes (P.cacheNodes counts 64-byte halves)
     if (COMPACT) Sstage.nodes = reinterpret_cast<const PNode*>(P.qnodes);    // ... of the COMPACT kernel 32-byte nodes, two per unit
-    const SceneCache SC = stage_scene_cache(Sstage, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights, P.leaves, P.cacheLeaves);      // contains the only barrier
-    lds_cf4* leafTable = (lds_cf4*)(pt_smem + attrOff + P.cacheAttrs * 80 + P.cacheMats * 96 + P.cacheLights * 64);      // FLAT kernels (attrOff > 0 there)
+    const SceneCache SC = stage_scene_cache(Sstage, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights);      // contains the only barrier
     if constexpr (ATTRLDS) {
         // The bounce reads its records through S; pointing S at the LDS copies makes those loads ds_reads (the address
         // space is visible to the compiler: everything below is inlined into this function).
@@ -376,15 +371,15 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(0);
         if (__ballot(hasExt || hasShadow) == 0ull) break;
         if constexpr (DEFER && FLAT) {
-            trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c, P.cacheNodes, leafTable, P.cacheLeaves);
+            trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c, P.cacheNodes, P.leaves, P.nLeaves);
 #ifdef PT_DIAG_DOUBLE_PAIR          // cost measurement only: the pair pass run twice, same result
-            { Hit h2; V3 thr2; trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr2, h2, c, P.cacheNodes, leafTable, P.cacheLeaves);
+            { Hit h2; V3 thr2; trace_pair_flat<STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr2, h2, c, P.cacheNodes, P.leaves, P.nLeaves);
               if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); thr.x = fminf_(thr.x, thr2.x); }
 #endif
         }
         else if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
         else if constexpr (FLAT) {
-            trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes, leafTable, P.cacheLeaves);
+            trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes, P.leaves, P.nLeaves);
 #ifdef PT_DIAG_DOUBLE_CLOSEST       // cost measurement only: the closest-hit traversal run twice, same result
             { Hit h2; trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h2, c, P.cacheNodes); if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); }
 #endif

@@ -65,7 +65,7 @@ struct KParams {
     const WNode* wnodes;
     int compact;                   // 1: megakernel_hbm_compact — the SIMPLE kernel for scenes in HBM on 32-byte quantised nodes (pt_trace.h: trace_resume_q)
     const QNode* qnodes; const void* leafBox; const int32_t* mids; QFrame qframe;
-    int cacheLeaves;               // FLAT kernels: PLeaf records staged behind them (0 = none: the lockstep node walk)
+    int nLeaves;                   // FLAT kernels: PLeaf records in global memory, read through the scalar cache (0 = none: the lockstep node walk)
     const PLeaf* leaves;
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
     int triKeep;                   // ... and its triangle loop once no more than entered * triKeep / 16 lanes still have triangles in their leaf
@@ -159,7 +159,7 @@ hipError_t launch_probe_bsdf_eval(const DeviceScene& S, int n, const int* materi
 // waves a probe_closest/shadow launch of n rays uses (spill sizing)
 inline int probe_trace_blocks(int n) { return (n + 63) / 64; }
 inline int megakernel_blocks(int tileCount, int wgWaves = 4) { return (tileCount + wgWaves - 1) / wgWaves; }
-inline size_t attr_cache_bytes(int nAttrs, int nMats, int nLights, int nLeaves = 0) { return (size_t)nAttrs * 80 + (size_t)nMats * 96 + (size_t)nLights * 64 + (size_t)nLeaves * 32; }
+inline size_t attr_cache_bytes(int nAttrs, int nMats, int nLights) { return (size_t)nAttrs * 80 + (size_t)nMats * 96 + (size_t)nLights * 64; }
 inline size_t megakernel_lds_bytes(int cacheNodes, int cacheTris, int stackEntries = kStackLds, int wgWaves = 4, size_t attrBytes = 0, bool mediumStacks = true) {
     return (size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * ((size_t)stackEntries * 256 + (mediumStacks ? (size_t)kMediumMax * 64 : 0)) + attrBytes;
 }

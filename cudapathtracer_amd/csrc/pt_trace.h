@@ -154,6 +154,32 @@ PT_DEV TriData load_tri(const DeviceScene& S, const SceneCache& C, int32_t i) {
     return t;
 }
 
+// The dealt-out tests of the FLAT kernels need v0, e1, e2 — 36 of a PTri's 48 bytes: two 16-byte LDS reads and one word, a
+// quarter less LDS return per test (C2: 109.7 -> 107.8 ms at 128 spp, profiles/r02_phase_census.md).
+struct TriEdges { f4v a, b; float e2z; };
+PT_DEV TriEdges load_tri_edges(const SceneCache& C, int32_t i) {
+    TriEdges t;
+    lds_cf4* p = C.tris + i * 3;
+    t.a = p[0]; t.b = p[1];
+    t.e2z = *reinterpret_cast<__attribute__((address_space(3))) const float*>(p + 2);
+    return t;
+}
+// A leaf's box and triangle range for the FLAT kernels' wave-uniform loop over the leaves, read from the table in GLOBAL memory
+// through the constant address space: a uniform address there is an s_load, the record arrives in SGPRs and the slab tests
+// take its fields as their scalar operand — no LDS broadcast (1 KB of LDS return per leaf and wave), no VGPRs and no
+// v_readfirstlane for it. The LDS pipeline of a CU is busy half of the headline kernel's time (SQ_LDS_IDX_ACTIVE): C2 111.4 ->
+// 109.4 ms at 128 spp.
+struct LeafBox { float mnx, mny, mnz, mxx, mxy, mxz; int32_t first, count; };
+PT_DEV LeafBox leaf_box(const PLeaf* __restrict__ leaves, int k) {
+    typedef __attribute__((address_space(4))) const float konst_f;         // read-only for the kernel's lifetime
+    typedef __attribute__((address_space(4))) const int32_t konst_i;
+    konst_f* p = (konst_f*)(uintptr_t)(leaves + k);
+    LeafBox L;
+    L.mnx = p[0]; L.mny = p[1]; L.mnz = p[2]; L.mxx = p[3]; L.mxy = p[4]; L.mxz = p[5];
+    L.first = ((konst_i*)p)[6]; L.count = ((konst_i*)p)[7];
+    return L;
+}
+
 // ---- leaving a loop before its last lane -------------------------------------------------------
 // A wave walks `while (cur >= 0) descend` until its LAST lane has reached a leaf, then the triangle loop until
 // the longest leaf is done. Without culling a ray pierces many boxes between two leaves, the counts differ
@@ -493,7 +519,7 @@ PT_DEV bool inv_is_regular(V3 inv) {
 // below the left / right child (patched in by the host for scenes that qualify, pt_api.hip).
 template <int N, int W = 1>
 PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool active, V3 o, V3 d, float max_t, Stack<N>& st, Hit& hit, Ctr& c, int nInternal,
-                               lds_cf4* leaves = nullptr, int nLeaves = 0) {
+                               const PLeaf* __restrict__ leaves = nullptr, int nLeaves = 0) {
     static_assert(N >= 11 + 2 * W, "the scratch layout needs (11 + 2 W) x 64 words of the wave's stack");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     typedef BitSet<W> Set;
@@ -507,10 +533,10 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     if (S.rootRef < 0) { if (active) tm = Set::range(0, S.nTris); }      // the root is the only leaf
     else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64(active && !inv_is_regular(inv)) == 0ull) {
         for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes (see inv_is_regular): wave-uniform loop
-            const f4v a = leaves[2 * k], b = leaves[2 * k + 1];   // uniform address: LDS broadcasts
+            const LeafBox L = leaf_box(leaves, k);               // through the scalar cache: SGPR operands of the slab test
             float t0;
-            const bool hitL = slab(a.x, a.y, a.z, a.w, b.x, b.y, o, inv, t0) && active;
-            tm.or_if(hitL, Set::range(__builtin_amdgcn_readfirstlane(f2i(b.z)), __builtin_amdgcn_readfirstlane(f2i(b.w))));
+            const bool hitL = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, o, inv, t0) && active;
+            tm.or_if(hitL, Set::range(L.first, L.count));
         }
     } else {
         Set vis = Set::zero();
@@ -576,9 +602,9 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
             }
             const int ti = rem.first();
             rem.clear_first();
-            const TriData q = load_tri<true>(S, C, ti);
+            const TriEdges q = load_tri_edges(C, ti);
             float t, u, v;
-            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), ro, rd, t, u, v);
+            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
             if (ok && (t < max_t)) {
                 const uint64_t tb = (uint64_t)f2u(t) << 32;           // t > 0: the bit pattern orders like the value
                 __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -647,7 +673,7 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
 //   prefix (128), the two u64 keys of the extension rays (2 x 128 words), the occlusion flags (64).
 template <int N>
 PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>& st, bool hasShadow, V3 so, V3 sd, float smaxt,
-                            bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal, lds_cf4* leaves = nullptr, int nLeaves = 0) {
+                            bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal, const PLeaf* __restrict__ leaves = nullptr, int nLeaves = 0) {
     static_assert(N >= 25, "the scratch layout needs 25 x 64 words of the wave's stack area");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     const int lane = (int)(threadIdx.x & 63u);
@@ -659,11 +685,11 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     if (S.rootRef < 0) { const uint64_t all = ~0ull >> (64 - S.nTris); tmE = hasExt ? all : 0ull; tmS = hasShadow ? all : 0ull; }
     else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64((hasExt && !inv_is_regular(invE)) || (hasShadow && !inv_is_regular(invS))) == 0ull) {
         for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes, both rays (see inv_is_regular)
-            const f4v a = leaves[2 * k], b = leaves[2 * k + 1];
+            const LeafBox L = leaf_box(leaves, k);                // through the scalar cache: SGPR operands of the slab tests
             float t0;
-            const bool eH = slab(a.x, a.y, a.z, a.w, b.x, b.y, eo, invE, t0) && hasExt;
-            const bool sH = slab(a.x, a.y, a.z, a.w, b.x, b.y, so, invS, t0) && hasShadow;
-            const int first = __builtin_amdgcn_readfirstlane(f2i(b.z)), cnt = __builtin_amdgcn_readfirstlane(f2i(b.w));
+            const bool eH = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, eo, invE, t0) && hasExt;
+            const bool sH = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, so, invS, t0) && hasShadow;
+            const int first = L.first, cnt = L.count;
             const uint64_t m = (~0ull >> (64 - cnt)) << (uint32_t)first;
             tmE |= eH ? m : 0ull; tmS |= sH ? m : 0ull;
         }
@@ -738,9 +764,9 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
             while (rem == 0ull) { l++; fetch(l); }                // next ray that has tests (there is one: p < total)
             const int ti = __builtin_ctzll(rem);
             rem &= rem - 1ull;
-            const TriData q = load_tri<true>(S, C, ti);
+            const TriEdges q = load_tri_edges(C, ti);
             float t, u, v;
-            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), ro, rd, t, u, v);
+            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
             if (ok && (t < rmax)) {
                 if (l < 64) {
                     const uint64_t tb = (uint64_t)f2u(t) << 32;
