@@ -56,7 +56,7 @@ struct DevBuf {
 struct pt_scene {
     int device = 0;
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves, wnodes, qnodes, leafBox, mids;
-    bool compactTried = false, compactOk = false, compactWanted = false; QFrame qframe{};   // 32-byte quantised nodes of trace_resume_q ("compact" 1)
+    bool compactTried = false, compactOk = false, compactWanted = false;   // 32-byte quantised nodes of trace_resume_q ("compact" 1)
     int nWide = 0, wideStackNeed = 0; bool wideTried = false, wideWanted = false;   // the 4-wide collapsed tree of trace_resume_w4 ("wide" 1: opt-in, measured slower)
     int nLeaves = 0;                                  // FLAT scenes: the leaf table (pt_trace.h: visited(leaf) == slab(leaf's own box))
     DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
@@ -593,44 +593,16 @@ static int ensure_wide(pt_scene* s) {
 }
 
 // The compact form of the tree for trace_resume_q (pt_trace.h), built once per scene from the packed binary records: per
-// internal node a QNode (both child boxes in 16-bit fixed point in one frame for the whole scene, rounded OUTWARD with
-// the very fmaf the kernel decodes with), per leaf its exact float box (at the index of its first packed triangle) and per
-// internal node the first triangle of its right subtree (the tie rule's walk).
+// internal node a QNode (both child boxes as 8-bit offsets in the node's own frame, rounded OUTWARD with the very fmaf the
+// kernel decodes with), per leaf its exact float box (at the index of its first packed triangle) and per internal node the
+// first triangle of its right subtree (the tie rule's walk).
 static int ensure_compact(pt_scene* s) {
     if (s->compactTried) return 0;
     s->compactTried = true;
     const int nI = s->nInternal, nT = s->nTrisPacked;
-    if (nI <= 0 || s->ds.rootRef != 0) return 0;
+    if (nI <= 0 || s->ds.rootRef != 0 || nI >= (1 << 24) || nT >= (1 << 24)) return 0;
     std::vector<PNode> pn((size_t)nI);
     HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nI * sizeof(PNode), hipMemcpyDeviceToHost));
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; a++) { lo[a] = std::min(pn[0].lmin[a], pn[0].rmin[a]); hi[a] = std::max(pn[0].lmax[a], pn[0].rmax[a]); }
-    for (int i = 0; i < nI; i++)                                   // (nested boxes make the root's the extent; do not rely on it)
-        for (int a = 0; a < 3; a++) {
-            lo[a] = std::min(lo[a], std::min(pn[i].lmin[a], pn[i].rmin[a])); hi[a] = std::max(hi[a], std::max(pn[i].lmax[a], pn[i].rmax[a]));
-            if (!std::isfinite(pn[i].lmin[a]) || !std::isfinite(pn[i].lmax[a]) || !std::isfinite(pn[i].rmin[a]) || !std::isfinite(pn[i].rmax[a])) return 0;
-        }
-    float org[3], scl[3];
-    for (int a = 0; a < 3; a++) {
-        org[a] = lo[a];
-        float sc = (hi[a] - lo[a]) / 65535.0f;
-        if (!(sc > 0.0f)) sc = 1e-30f;
-        for (int k = 0; k < 64 && std::fmaf(65535.0f, sc, org[a]) < hi[a]; k++) sc = std::nextafter(sc, INFINITY);
-        if (std::fmaf(65535.0f, sc, org[a]) < hi[a] || !std::isfinite(sc)) return 0;
-        scl[a] = sc;
-    }
-    auto down = [&](float x, int a) {                              // largest q with decode(q) <= x
-        int q = (int)std::floor(((double)x - org[a]) / scl[a]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q > 0 && std::fmaf((float)q, scl[a], org[a]) > x) q--;
-        return (uint16_t)q;
-    };
-    auto up = [&](float x, int a) {                                // smallest q with decode(q) >= x
-        int q = (int)std::ceil(((double)x - org[a]) / scl[a]);
-        q = std::min(std::max(q, 0), 65535);
-        while (q < 65535 && std::fmaf((float)q, scl[a], org[a]) < x) q++;
-        return (uint16_t)q;
-    };
     std::vector<QNode> qn((size_t)nI);
     std::vector<float> lb((size_t)nT * 8, 0.0f);                   // two 16-byte halves per packed triangle index; filled at the first of each leaf
     std::vector<int32_t> mids((size_t)nI, 0), minFirst((size_t)nI, 0), maxFirst((size_t)nI, 0);
@@ -638,39 +610,67 @@ static int ensure_compact(pt_scene* s) {
     for (int i = nI - 1; i >= 0 && ok; i--) {                      // children come after their parent (breadth-first numbering): bottom-up
         const PNode& p = pn[i];
         QNode& q = qn[i];
-        for (int a = 0; a < 3; a++) { q.lmin[a] = down(p.lmin[a], a); q.lmax[a] = up(p.lmax[a], a); q.rmin[a] = down(p.rmin[a], a); q.rmax[a] = up(p.rmax[a], a); }
-        q.left = p.left; q.right = p.right;
+        float org[3], ext = 0.0f;
+        for (int a = 0; a < 3 && ok; a++) {
+            ok = std::isfinite(p.lmin[a]) && std::isfinite(p.lmax[a]) && std::isfinite(p.rmin[a]) && std::isfinite(p.rmax[a]);
+            org[a] = std::min(p.lmin[a], p.rmin[a]);
+            ext = std::max(ext, std::max(p.lmax[a], p.rmax[a]) - org[a]);
+        }
+        if (!ok) break;
+        int k = -64;                                               // step 2^k: the smallest with fma(255, 2^k, origin) >= the node's maximum on every axis
+        if (ext > 0.0f) { int e; std::frexp(ext / 255.0f, &e); k = std::max(e - 1, -64); }
+        for (; k <= 63; k++) {
+            const float sc = std::ldexp(1.0f, k);
+            bool fits = true;
+            for (int a = 0; a < 3; a++) fits = fits && std::fmaf(255.0f, sc, org[a]) >= std::max(p.lmax[a], p.rmax[a]);
+            if (fits) break;
+        }
+        if (k > 63) { ok = false; break; }
+        const float sc = std::ldexp(1.0f, k);
+        auto down = [&](float x, int a) {                          // largest q with decode(q) <= x
+            int v = (int)std::floor(((double)x - org[a]) / sc);
+            v = std::min(std::max(v, 0), 255);
+            while (v > 0 && std::fmaf((float)v, sc, org[a]) > x) v--;
+            return (uint8_t)v;
+        };
+        auto up = [&](float x, int a) {                            // smallest q with decode(q) >= x
+            int v = (int)std::ceil(((double)x - org[a]) / sc);
+            v = std::min(std::max(v, 0), 255);
+            while (v < 255 && std::fmaf((float)v, sc, org[a]) < x) v++;
+            return (uint8_t)v;
+        };
+        for (int a = 0; a < 3; a++) {
+            q.o[a] = org[a];
+            q.lmin[a] = down(p.lmin[a], a); q.lmax[a] = up(p.lmax[a], a); q.rmin[a] = down(p.rmin[a], a); q.rmax[a] = up(p.rmax[a], a);
+            auto dec = [&](uint8_t v) { return std::fmaf((float)v, sc, org[a]); };
+            ok = ok && dec(q.lmin[a]) <= p.lmin[a] && dec(q.lmax[a]) >= p.lmax[a] && dec(q.rmin[a]) <= p.rmin[a] && dec(q.rmax[a]) >= p.rmax[a];
+        }
         int mn[2], mx[2];
+        uint32_t word[2];
         const int32_t ref[2] = {p.left, p.right};
-        for (int k = 0; k < 2 && ok; k++) {
-            if (ref[k] >= 0) { ok = ref[k] > i && ref[k] < nI; if (ok) { mn[k] = minFirst[ref[k]]; mx[k] = maxFirst[ref[k]]; } }
-            else {
-                const int f = ~ref[k];
-                ok = ref[k] != kRefNone && f >= 0 && f < nT;
+        for (int c = 0; c < 2 && ok; c++) {
+            if (ref[c] >= 0) {
+                ok = ref[c] > i && ref[c] < nI;
+                if (ok) { mn[c] = minFirst[ref[c]]; mx[c] = maxFirst[ref[c]]; word[c] = (uint32_t)ref[c]; }
+            } else {
+                const int f = ~ref[c];
+                ok = ref[c] != kRefNone && f >= 0 && f < nT;
                 if (!ok) break;
-                mn[k] = mx[k] = f;
-                const float* bmn = k == 0 ? p.lmin : p.rmin; const float* bmx = k == 0 ? p.lmax : p.rmax;
+                mn[c] = mx[c] = f; word[c] = 0x80000000u | (uint32_t)f;
+                const float* bmn = c == 0 ? p.lmin : p.rmin; const float* bmx = c == 0 ? p.lmax : p.rmax;
                 float* o = &lb[(size_t)f * 8];
                 o[0] = bmn[0]; o[1] = bmn[1]; o[2] = bmn[2]; o[3] = bmx[0]; o[4] = bmx[1]; o[5] = bmx[2];
             }
         }
         if (!ok) break;
+        q.left = word[0] | ((uint32_t)(k + 64) << 24); q.right = word[1];
         ok = mx[0] < mn[1];                                        // leaf order is left to right
         minFirst[i] = mn[0]; maxFirst[i] = mx[1]; mids[i] = mn[1];
-    }
-    if (!ok) return 0;
-    for (int i = 0; i < nI && ok; i++) {                           // every decoded box contains the float box
-        const PNode& p = pn[i]; const QNode& q = qn[i];
-        for (int a = 0; a < 3; a++) {
-            auto dec = [&](uint16_t v) { return std::fmaf((float)v, scl[a], org[a]); };
-            ok = ok && dec(q.lmin[a]) <= p.lmin[a] && dec(q.lmax[a]) >= p.lmax[a] && dec(q.rmin[a]) <= p.rmin[a] && dec(q.rmax[a]) >= p.rmax[a];
-        }
     }
     if (!ok) return 0;
     if (int r = upload(s->qnodes, qn.data(), qn.size() * sizeof(QNode))) return r;
     if (int r = upload(s->leafBox, lb.data(), lb.size() * sizeof(float))) return r;
     if (int r = upload(s->mids, mids.data(), mids.size() * sizeof(int32_t))) return r;
-    s->qframe = QFrame{org[0], org[1], org[2], scl[0], scl[1], scl[2]};
     s->compactOk = true;
     return 0;
 }
@@ -732,7 +732,6 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (wide) P.cacheNodes = 2 * std::min(s->nWide, kCacheBytesHbmSimple / 128);            // wide nodes, counted in 64-byte halves
     P.compact = compact ? 1 : 0;
     P.qnodes = compact ? (const QNode*)s->qnodes.p : nullptr; P.leafBox = compact ? s->leafBox.p : nullptr; P.mids = compact ? (const int32_t*)s->mids.p : nullptr;
-    P.qframe = s->qframe;
     if (compact) P.cacheNodes = std::min(s->nInternal & ~1, kCacheBytesHbmSimple / 32) / 2;     // compact nodes, two per 64-byte unit
     P.xcdBands = s->xcdBands ? 1 : 0;
     P.S.stackSpill = spillEntries;

@@ -173,15 +173,17 @@ struct __attribute__((aligned(128))) WNode {
 };
 static_assert(sizeof(WNode) == 128, "WNode");
 
-// Compact internal node for the SIMPLE kernel for scenes in HBM (pt_trace.h: trace_resume_q): both children's boxes as 16-bit
-// fixed point in ONE frame for the whole scene (x = fma(q, scale, origin)), rounded OUTWARD so that each decoded box contains
-// the reference's float box; refs as in PNode. Half a PNode: two 16-byte loads per visit instead of four.
+// Compact internal node for the SIMPLE kernel for scenes in HBM (pt_trace.h: trace_resume_q): both children's boxes as 8-bit
+// offsets in the node's OWN frame — origin = the node's box minimum (exact floats), one power-of-two step for all three axes,
+// x = fma(q, 2^k, origin) — rounded OUTWARD so that each decoded box contains the reference's float box: the step is 1/255
+// of the node's largest extent at every depth. Child words: bit 31 = leaf, bits 24-30 of `left` = k + 64, bits 0-23 = the
+// node index or the leaf's first packed triangle. Half a PNode: two 16-byte loads per visit instead of four.
 struct __attribute__((aligned(16))) QNode {
-    uint16_t lmin[3], lmax[3], rmin[3], rmax[3];
-    int32_t left, right;
+    float o[3];
+    uint8_t lmin[3], lmax[3], rmin[3], rmax[3];
+    uint32_t left, right;
 };
 static_assert(sizeof(QNode) == 32, "QNode");
-struct QFrame { float ox, oy, oz, sx, sy, sz; };
 
 // FLAT kernels: one record per LEAF of the tree — the leaf's own box (as stored with its parent) and its triangle range.
 struct __attribute__((aligned(16))) PLeaf {

@@ -327,7 +327,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
             if constexpr (COMPACT) {
-                const Compact K{P.qnodes, reinterpret_cast<const f4v*>(P.leafBox), P.mids, P.qframe};
+                const Compact K{P.qnodes, reinterpret_cast<const f4v*>(P.leafBox), P.mids};
                 trace_resume_q<STACKN>(S, SC, K, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, Keep{P.nodeKeep, P.triKeep});
                 PT_STAMP(1);
                 continue;

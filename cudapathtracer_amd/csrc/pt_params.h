@@ -64,7 +64,7 @@ struct KParams {
     int wide;                      // 1: megakernel_hbm_wide — the SIMPLE kernel for scenes in HBM on the 4-wide collapsed tree `wnodes`
     const WNode* wnodes;
     int compact;                   // 1: megakernel_hbm_compact — the SIMPLE kernel for scenes in HBM on 32-byte quantised nodes (pt_trace.h: trace_resume_q)
-    const QNode* qnodes; const void* leafBox; const int32_t* mids; QFrame qframe;
+    const QNode* qnodes; const void* leafBox; const int32_t* mids;
     int nLeaves;                   // FLAT kernels: PLeaf records in global memory, read through the scalar cache (0 = none: the lockstep node walk)
     const PLeaf* leaves;
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation

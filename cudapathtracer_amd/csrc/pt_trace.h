@@ -1197,20 +1197,21 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
 
 // ---- compact nodes (SIMPLE scenes in HBM) --------------------------------------------------------
 // visited(leaf) == slab(leaf's own box) for a ray with a regular 1 / d (see inv_is_regular): the boxes ABOVE the leaves only
-// have to contain them. So the inner nodes can be stored smaller than the reference stores them — QNode: 16-bit fixed
-// point, rounded outward, 32 bytes, two 16-byte loads per visit instead of four, twice as many nodes per cache line and in
-// the LDS copy of the top of the tree — as long as a leaf is entered only if its EXACT box passes (leafBox, 2 loads per
+// have to contain them. So the inner nodes can be stored smaller than the reference stores them — QNode: 8-bit offsets in
+// the node's own frame, rounded outward, 32 bytes, two 16-byte loads per visit instead of four, twice as many nodes per
+// cache line and in the LDS copy of the top of the tree — as long as a leaf is entered only if its EXACT box passes (leafBox, 2 loads per
 // candidate leaf) and the result is the reference's: minimum t, and where two triangles return the same t the one the
 // reference visits first — decided, when it happens, by walking the reference's own nodes (exact boxes, PNode.pad0 = first
 // triangle of the right subtree) down to where the two leaves part and asking which child the reference enters first
 // (`tL < tR`, else the right one). Lanes whose ray has a zero direction component (`exact`) fetch the reference's PNodes
 // instead, in the same loop. Shadow rays of a NOLEAF scene are occluded by any hit.
-// MEASURED (profiles/r02_ab_compact.log): bit-identical frames, and SLOWER — 82 k triangles 214 -> 260 ms (32 spp), 263 k
-// triangles 199 -> 240 ms (8 spp). Cache-line accesses per ray fall by a third, wave-level VALU instructions rise by a fifth
-// (unpack + convert + fma per plane), and the time follows the instructions: the kernel for scenes in HBM is not bound by
-// its L1 line rate alone. Loading a leaf's first triangle together with its box (one latency step instead of
-// two) is another 3 % slower. Not the default: option "compact" = 1 to reproduce.
-struct Compact { const QNode* q; const f4v* leafBox; const int32_t* mids; QFrame f; };
+// MEASURED (profiles/r02_ab_compact.log): bit-identical frames, and SLOWER — 82 k triangles 212 -> 259 ms (32 spp), 263 k
+// triangles 199 -> 239 ms (8 spp), with the 16-bit global grid of the first version as with these per-node frames. Load
+// instructions -23 %, the TA's busy cycles -11 % (a lane's first 16 bytes of a line cost it ~1.7 cycles, each further 16
+// bytes ~0.76: half the bytes are not half the cost), VALU instructions +58 % (the node loop is this kernel's instruction
+// stream, and the decode adds ~40 to its ~65 per trip): DESIGN.md §6. Loading a leaf's first triangle together with its box
+// (one latency step instead of two) is another 3 % slower. Not the default: option "compact" = 1 to reproduce.
+struct Compact { const QNode* q; const f4v* leafBox; const int32_t* mids; };
 
 PT_DEV bool tie_keeps_first(const DeviceScene& S, const int32_t* __restrict__ mids, V3 o, V3 inv, int tiBest, int tiNew) {
     // both triangles returned the same t: true if the reference visits tiBest's before tiNew's (packed indices, leaf order)
@@ -1236,7 +1237,6 @@ PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Comp
     if (!(r.flags & kRayBusy)) return;
     const QNode* __restrict__ Q = K.q;
     const f4v* __restrict__ leafBox = K.leafBox;
-    const QFrame F = K.f;
     int bestTi = r.pend;                                           // the packed index of the best hit so far (for the tie rule)
     bool inLeaf = (r.flags & kRayInLeaf) != 0;                     // `cur` resumes a leaf whose own box has been tested
     V3 o = r.o, d = r.d, inv = r.inv;
@@ -1262,12 +1262,14 @@ PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Comp
                 f4v q0, q1;
                 if (cur < nLdsQ) { lds_cf4* p = C.nodes + cur * 2; q0 = p[0]; q1 = p[1]; }
                 else { const f4v* p = reinterpret_cast<const f4v*>(Q + cur); q0 = p[0]; q1 = p[1]; }
-                const uint32_t w0 = f2u(q0.x), w1 = f2u(q0.y), w2 = f2u(q0.z), w3 = f2u(q0.w), w4 = f2u(q1.x), w5 = f2u(q1.y);
-                b[0] = __builtin_fmaf((float)(w0 & 0xffffu), F.sx, F.ox); b[1] = __builtin_fmaf((float)(w0 >> 16), F.sy, F.oy); b[2] = __builtin_fmaf((float)(w1 & 0xffffu), F.sz, F.oz);
-                b[3] = __builtin_fmaf((float)(w1 >> 16), F.sx, F.ox); b[4] = __builtin_fmaf((float)(w2 & 0xffffu), F.sy, F.oy); b[5] = __builtin_fmaf((float)(w2 >> 16), F.sz, F.oz);
-                b[6] = __builtin_fmaf((float)(w3 & 0xffffu), F.sx, F.ox); b[7] = __builtin_fmaf((float)(w3 >> 16), F.sy, F.oy); b[8] = __builtin_fmaf((float)(w4 & 0xffffu), F.sz, F.oz);
-                b[9] = __builtin_fmaf((float)(w4 >> 16), F.sx, F.ox); b[10] = __builtin_fmaf((float)(w5 & 0xffffu), F.sy, F.oy); b[11] = __builtin_fmaf((float)(w5 >> 16), F.sz, F.oz);
-                left = f2i(q1.z); right = f2i(q1.w);
+                const uint32_t w0 = f2u(q0.w), w1 = f2u(q1.x), w2 = f2u(q1.y), wl = f2u(q1.z), wr = f2u(q1.w);
+                const float sc = __builtin_bit_cast(float, (((wl >> 24) & 0x7fu) + 63u) << 23);             // 2^k, k = field - 64
+                b[0] = __builtin_fmaf((float)(w0 & 0xffu), sc, q0.x); b[1] = __builtin_fmaf((float)((w0 >> 8) & 0xffu), sc, q0.y); b[2] = __builtin_fmaf((float)((w0 >> 16) & 0xffu), sc, q0.z);
+                b[3] = __builtin_fmaf((float)(w0 >> 24), sc, q0.x); b[4] = __builtin_fmaf((float)(w1 & 0xffu), sc, q0.y); b[5] = __builtin_fmaf((float)((w1 >> 8) & 0xffu), sc, q0.z);
+                b[6] = __builtin_fmaf((float)((w1 >> 16) & 0xffu), sc, q0.x); b[7] = __builtin_fmaf((float)(w1 >> 24), sc, q0.y); b[8] = __builtin_fmaf((float)(w2 & 0xffu), sc, q0.z);
+                b[9] = __builtin_fmaf((float)((w2 >> 8) & 0xffu), sc, q0.x); b[10] = __builtin_fmaf((float)((w2 >> 16) & 0xffu), sc, q0.y); b[11] = __builtin_fmaf((float)(w2 >> 24), sc, q0.z);
+                const int32_t vl = (int32_t)(wl & 0xffffffu), vr = (int32_t)(wr & 0xffffffu);
+                left = (int32_t)wl < 0 ? ~vl : vl; right = (int32_t)wr < 0 ? ~vr : vr;
             }
             float tL, tR;
             const bool hL = slab(b[0], b[1], b[2], b[3], b[4], b[5], o, inv, tL);
