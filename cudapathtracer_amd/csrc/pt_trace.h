@@ -755,7 +755,8 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
         rmax = __builtin_bit_cast(float, Wd[6 * 128 + v]);
     };
     if (p < pEnd) {
-        for (int sft = 64; sft; sft >>= 1) { const int cand = l + sft; if (Wd[kPre + cand] <= p) l = cand; }     // owner of test p among the 128 entries
+        l = p >= totalE ? 64 : 0;                                  // owner of test p among the 128 entries: the shadow rays' tests start at totalE,
+        for (int sft = 32; sft; sft >>= 1) { const int cand = l + sft; if (Wd[kPre + cand] <= p) l = cand; }     // six dependent LDS reads for the rest
         fetch(l);
         rem &= ~((1ull << select64(rem, p - Wd[kPre + l])) - 1ull);
     }
