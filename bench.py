@@ -182,6 +182,10 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
         rf = RF.l1_roofline(gnodes, cnt["tri_tests"], kernel_ms)
         rf["global_node_fetches_per_launch"] = gnodes
         rf["global_tri_tests_per_launch"] = cnt["tri_tests"]
+        busy = RF.ta_busy(entry)                                 # from the committed PMC pass of this workload: how busy the unit behind this bound was
+        if busy is not None:
+            rf["ta_busy_frac"] = busy
+            rf["profile"] = {"file": "profiles/roofline_inputs.json", "workload": workload, "spp": spp, "source": entry.get("source")}
     else:
         rf = RF.valu_roofline(entry, kernel_ms)
         if rf is None:                                           # no PMC pass of this exact workload / kernel is committed

@@ -9,8 +9,10 @@ tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p $out
 SQ="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU"
-run_pmc() {  # workload spp name
-  bash tools/pmc_passes.sh $out/pmc_$3 $1 $2 "$SQ" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"
+run_pmc() {  # workload spp name [more passes: one quoted counter list each]
+  wl=$1; sp=$2; nm=$3; shift 3
+  bash tools/pmc_passes.sh $out/pmc_$nm $wl $sp "$SQ" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "$@"
+  set -- $wl $sp $nm
   ms=$(python - <<PY
 import csv,glob
 rows=[r for f in glob.glob("$out/pmc_$3/pass2/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
@@ -24,8 +26,8 @@ PY
   echo "pmc $3 done (kernel under the profiler $ms ms)"
 }
 run_pmc cornell_1920x1080_1024spp_depth8_mis 1024 cornell
-run_pmc atrium262k_1920x1080_4096spp_depth16_mis 32 atrium_spp32
-run_pmc blob82k_1920x1080_1024spp_depth8_mis 1024 blob
+run_pmc atrium262k_1920x1080_4096spp_depth16_mis 32 atrium_spp32 "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"      # scenes in HBM: how busy the texture addresser is
+run_pmc blob82k_1920x1080_1024spp_depth8_mis 1024 blob "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"
 cp profiles/roofline_inputs.json $out/roofline_inputs.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/stats.log 2>&1 )
 python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err

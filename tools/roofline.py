@@ -18,7 +18,8 @@ Which roofline binds which kernel ("Roofline"):
     tag rate: a divergent 16-byte load costs one cache-line access per lane, and a CU retires ONE line access per clock
     (tools/ta_rate/quad_fetch.hip: 152 G 64-byte records/s = 609 G line accesses/s chip-wide). peak = 256 CUs x 2.4 GHz =
     614.4 G accesses/s. achieved = (4 per internal-node fetch that missed the LDS scene cache + 3 per triangle test)
-    / duration — counted live by the counting pass of bench.py (pt_debug_stamps()[0], tri_tests).
+    / duration — counted live by the counting pass of bench.py (pt_debug_stamps()[0], tri_tests). `ta_busy_frac` next to it
+    is TA_TA_BUSY / TCP_GATE_EN1 of the committed PMC pass of the same workload: how busy the unit behind the bound was.
 
 SURVEY §8(d)'s ALGORITHMIC bytes (32 B/box test + 16 B/node + 52 B/triangle test + 96 B/hit + 16 B/pixel) stay in the bench
 line as a labelled secondary figure: divided by the HBM peak they exceed 1 on every scene here, because those bytes are served
@@ -91,6 +92,14 @@ def l1_roofline(global_node_fetches, global_tri_tests, kernel_ms):
     achieved = lines / (kernel_ms * 1e-3)
     return {"bound": "l1_lines", "achieved": achieved / 1e9, "peak": PEAK_L1_LINES / 1e9, "unit": "Gline-access/s", "frac": achieved / PEAK_L1_LINES,
             "line_accesses_per_launch": lines}
+
+
+def ta_busy(entry):
+    """Scenes in HBM: the fraction of its cycles a CU's texture addresser (the unit the L1 line rate belongs to) was busy in the
+    profiled launch — TA_TA_BUSY summed over the CUs / TCP_GATE_EN1 summed over the CUs (the L1's clock). None without both."""
+    if not entry or not entry.get("TA_TA_BUSY_sum") or not entry.get("TCP_GATE_EN1_sum"):
+        return None
+    return entry["TA_TA_BUSY_sum"] / entry["TCP_GATE_EN1_sum"]
 
 
 def algorithmic(own_bytes, kernel_ms):
