@@ -56,7 +56,8 @@ struct DevBuf {
 struct pt_scene {
     int device = 0;
     DevBuf nodes, tris, attrs, lights, mats, textures, jump, totals, leaves, wnodes, qnodes, leafBox, mids;
-    bool compactTried = false, compactOk = false, compactWanted = false;   // 32-byte quantised nodes of trace_resume_q ("compact" 1)
+    bool compactTried = false, compactOk = false, compactWanted = false;
+    int wfWideWg = 1;                                                                 // wavefront trace kernel: 16-wave workgroups for scenes in HBM ("wf_wide_wg")   // 32-byte quantised nodes of trace_resume_q ("compact" 1)
     int nWide = 0, wideStackNeed = 0; bool wideTried = false, wideWanted = false;   // the 4-wide collapsed tree of trace_resume_w4 ("wide" 1: opt-in, measured slower)
     int nLeaves = 0;                                  // FLAT scenes: the leaf table (pt_trace.h: visited(leaf) == slab(leaf's own box))
     DevBuf rng, spill, tilebuf, colors, pixcnt, queue, left; // work buffers, grown on demand
@@ -496,17 +497,19 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
         if (int r = s->wfCtr.ensure((size_t)W.n * 8 * sizeof(uint32_t))) return r;
         W.pathCtr = (uint32_t*)s->wfCtr.p;
     }
-    const int blocks = std::max(1, std::min(s->numCU * kWfBlocksPerCU, (W.n + 255) / 256));
+    // the trace kernel has its own LDS budget (no medium stacks, smaller traversal stack): the whole scene if it fits 12 KB, else
+    // the top of the tree — in 16-wave workgroups, two per CU, that share 48 KB of it (`wf_wide_wg` 0: the 4-wave shape)
+    int wfNodes, wfTris, wgWaves = 4;
+    if ((size_t)s->nInternal * 64 + (size_t)s->ds.nTris * 48 <= (size_t)kWfCacheBytes) { wfNodes = s->nInternal; wfTris = s->ds.nTris; }
+    else if (s->wfWideWg == 2 || (s->wfWideWg == 1 && (W.n + 1023) / 1024 >= s->numCU * 2)) { wgWaves = 16; wfNodes = std::min(s->nInternal, (80 * 1024 - 16 * kWfStackLds * 256) / 64); wfTris = 0; }
+    else { wfNodes = std::min(s->nInternal, kWfCacheBytes / 64); wfTris = 0; }
+    const int blocks = std::max(1, std::min(s->numCU * (32 / wgWaves), (W.n + 64 * wgWaves - 1) / (64 * wgWaves)));
     const int spillPerLane = std::max(0, s->stackNeed - kWfStackLds);
     int32_t* spill = nullptr;
     if (spillPerLane > 0) {
-        if (int r = s->wfSpill.ensure((size_t)blocks * 4 * spillPerLane * 64 * sizeof(int32_t))) return r;
+        if (int r = s->wfSpill.ensure((size_t)blocks * wgWaves * spillPerLane * 64 * sizeof(int32_t))) return r;
         spill = (int32_t*)s->wfSpill.p;
     }
-    // the trace kernel has its own LDS budget (no medium stacks, smaller traversal stack)
-    int wfNodes, wfTris;
-    if ((size_t)s->nInternal * 64 + (size_t)s->ds.nTris * 48 <= (size_t)kWfCacheBytes) { wfNodes = s->nInternal; wfTris = s->ds.nTris; }
-    else { wfNodes = std::min(s->nInternal, kWfCacheBytes / 64); wfTris = 0; }
     const CamK ck = cam_to_kernel(*cam);
     HIP_OK(hipMemsetAsync(W.qctl, 0, 16, stream));
     HIP_OK(hipEventRecord(s->ev0, stream));
@@ -522,7 +525,7 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
             HIP_OK(hipStreamSynchronize(stream));
             if (queued == 0) { finished = true; break; }
         }
-        HIP_OK(launch_wf_trace(count, blocks, W, s->ds, wfNodes, wfTris, spill, spillPerLane, (int)(it & 1), stream));
+        HIP_OK(launch_wf_trace(count, wgWaves, blocks, W, s->ds, wfNodes, wfTris, spill, spillPerLane, (int)(it & 1), stream));
     }
     if (!finished) return fail(-4, "wavefront render did not terminate within %lld iterations", cap);
     HIP_OK(launch_wf_finish(W, stream));
@@ -936,7 +939,7 @@ const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
     {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1}, {"wide", 0, 1},
-    {"compact", 0, 1},
+    {"compact", 0, 1}, {"wf_wide_wg", 0, 2},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -972,6 +975,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 18: s->leafBoxes = v != 0; break;
         case 19: s->wideWanted = v != 0; break;
         case 20: s->compactWanted = v != 0; break;
+        case 21: s->wfWideWg = v; break;
     }
     return 0;
 }
@@ -1000,6 +1004,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 18: *out = s->leafBoxes; break;
         case 19: *out = s->wideWanted; break;
         case 20: *out = s->compactWanted; break;
+        case 21: *out = s->wfWideWg; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

@@ -170,8 +170,10 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
 // Persistent traversal with lane-level refill. qctl[(it&1)*2] = number of queued rays,
 // qctl[(it&1)*2+1] = fetch cursor. The kernel also clears the OTHER counter pair for the next
 // iteration (nothing else touches it while this kernel runs).
-template <bool COUNT>
-__global__ void __launch_bounds__(256)
+// WGW: waves per workgroup — 4 (eight workgroups per CU, 12 KB of scene cache each) or, for scenes in HBM, 16 (two per CU sharing
+// a 48 KB copy of the top of the tree: 768 nodes instead of 192, as the megakernel's kernel for such scenes does).
+template <bool COUNT, int WGW>
+__global__ void __launch_bounds__(64 * WGW) __attribute__((amdgpu_waves_per_eu(8)))
 wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
     // stage the scene cache exactly like the megakernel
@@ -190,7 +192,7 @@ wf_trace_kernel(WfParams W, DeviceScene S, int cacheNodes, int cacheTris, int32_
     const int cacheBytes = cacheNodes * 64 + cacheTris * 48;
     Stack<kWfStackLds> st;
     st.lds = (lds_i32*)(wf_smem + cacheBytes) + wave * (kWfStackLds * 64) + lane;
-    st.spill = spill ? spill + ((size_t)(blockIdx.x * 4 + wave) * spillPerLane) * 64 + lane : nullptr;
+    st.spill = spill ? spill + ((size_t)(blockIdx.x * WGW + wave) * spillPerLane) * 64 + lane : nullptr;
     st.sp = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { W.qctl[((it + 1) & 1) * 2 + 0] = 0u; W.qctl[((it + 1) & 1) * 2 + 1] = 0u; }
 
@@ -304,10 +306,14 @@ hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const 
     }
     return hipGetLastError();
 }
-hipError_t launch_wf_trace(bool count, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it, hipStream_t s) {
-    const unsigned lds = (unsigned)((size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + 4 * (size_t)kWfStackLds * 256);
-    if (count) hipLaunchKernelGGL((wf_trace_kernel<true>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, spillPerLane, it);
-    else hipLaunchKernelGGL((wf_trace_kernel<false>), dim3(blocks), dim3(256), lds, s, W, S, cacheNodes, cacheTris, spill, spillPerLane, it);
+hipError_t launch_wf_trace(bool count, int wgWaves, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it, hipStream_t s) {
+    const unsigned lds = (unsigned)((size_t)cacheNodes * 64 + (size_t)cacheTris * 48 + (size_t)wgWaves * kWfStackLds * 256);
+#define PT_WF_LAUNCH(C, G) do { if (lds > 65536u) { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trace_kernel<C, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                                                    if (e_ != hipSuccess) return e_; } \
+                                hipLaunchKernelGGL((wf_trace_kernel<C, G>), dim3(blocks), dim3(64 * G), lds, s, W, S, cacheNodes, cacheTris, spill, spillPerLane, it); } while (0)
+    if (wgWaves == 16) { if (count) PT_WF_LAUNCH(true, 16); else PT_WF_LAUNCH(false, 16); }
+    else { if (count) PT_WF_LAUNCH(true, 4); else PT_WF_LAUNCH(false, 4); }
+#undef PT_WF_LAUNCH
     return hipGetLastError();
 }
 

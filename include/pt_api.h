@@ -198,6 +198,8 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
  *   "wide" 0|1            SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes (0: measured 10-30 % slower)
  *   "compact" 0|1         ... or 32-byte quantised inner nodes with exact leaf boxes (0: same frames, measured 20 % slower)
+ *   "wf_wide_wg" 0|1|2    wavefront variant, scenes in HBM: the trace kernel in 16-wave workgroups sharing 48 KB of the tree top (1: when
+ *                         the launch has enough paths to fill them, 2: always)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
  *   "flat2" 0|1           FLAT scenes (<= 64 triangles, no MAT_LEAF triangle), MIS integrator: shadow ray and next extension
  *                         ray in one FLAT pass (1)
