@@ -511,6 +511,8 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
         spill = (int32_t*)s->wfSpill.p;
     }
     const CamK ck = cam_to_kernel(*cam);
+    const bool wfSimple = s->simpleOk && s->simpleWanted && !count;        // the SIMPLE bounce (pt_path.h) in the logic kernel: diffuse-only scenes, timed launches
+    s->lastLaunchSimple = wfSimple ? 1 : 0;
     HIP_OK(hipMemsetAsync(W.qctl, 0, 16, stream));
     HIP_OK(hipEventRecord(s->ev0, stream));
     HIP_OK(launch_wf_init(W, spp, stream));
@@ -518,7 +520,7 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
     const long long cap = (long long)std::max(spp, 1) * 4200 + 64;
     bool finished = false;
     for (long long it = 0; it < cap; it++) {
-        HIP_OK(launch_wf_logic(integrator, count, W, s->ds, ck, maxDepth, useMIS, (int)(it & 1), stream));
+        HIP_OK(launch_wf_logic(integrator, count, wfSimple, W, s->ds, ck, maxDepth, useMIS, (int)(it & 1), stream));
         if ((it & 15) == 15) {
             uint32_t queued = 0;
             HIP_OK(hipMemcpyAsync(&queued, W.qctl + (it & 1) * 2, 4, hipMemcpyDeviceToHost, stream));

@@ -134,7 +134,7 @@ size_t wf_state_bytes(int n);
 void wf_carve(WfParams& W, void* base);
 hipError_t launch_wf_init(const WfParams& W, int spp, hipStream_t s);
 hipError_t launch_wf_finish(const WfParams& W, hipStream_t s);
-hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s);
+hipError_t launch_wf_logic(int integrator, bool count, bool simple, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s);
 hipError_t launch_wf_trace(bool count, int wgWaves, int blocks, const WfParams& W, const DeviceScene& S, int cacheNodes, int cacheTris, int32_t* spill, int spillPerLane, int it, hipStream_t s);
 hipError_t launch_wf_counters(const WfParams& W, uint32_t* pixCounters, unsigned long long* totals, hipStream_t s);
 

@@ -35,38 +35,44 @@ enum WfU : int {   // uint32 fields
 // results per RAY slot (extension ray of path p: slot p; shadow ray of path p: slot n + p)
 enum WfR : int { R_T, R_U, R_V, R_TRI, R_MAT, R_THRX, R_THRY, R_THRZ, R_POPS, R_BOXES, R_TRIS, R_COUNT };
 
+// SIMPLE (diffuse-only scenes, pt_path.h): the medium stack words, its top and the two indices of refraction are never read.
+template <bool SIMPLE = false>
 PT_DEV void wf_load(const WfParams& W, int p, PathState& ps, RegMedium& ms, V3& acc, int& samplesLeft) {
     const float* F = W.F + p; const uint32_t* U = W.U + p; const size_t n = W.n;
     ps.o = v3(F[F_OX * n], F[F_OY * n], F[F_OZ * n]); ps.d = v3(F[F_DX * n], F[F_DY * n], F[F_DZ * n]);
     ps.beta = v3(F[F_BX * n], F[F_BY * n], F[F_BZ * n]); ps.Li = v3(F[F_LIX * n], F[F_LIY * n], F[F_LIZ * n]);
     ps.prevPoint = v3(F[F_PPX * n], F[F_PPY * n], F[F_PPZ * n]); ps.woLocal = v3(F[F_WOX * n], F[F_WOY * n], F[F_WOZ * n]);
-    ps.pdf = F[F_PDF * n]; ps.etaI = F[F_ETAI * n]; ps.etaT = F[F_ETAT * n];
+    ps.pdf = F[F_PDF * n];
+    if (SIMPLE) { ps.etaI = kEps; ps.etaT = kEps; } else { ps.etaI = F[F_ETAI * n]; ps.etaT = F[F_ETAT * n]; }
     ps.so = v3(F[F_SOX * n], F[F_SOY * n], F[F_SOZ * n]); ps.sd = v3(F[F_SDX * n], F[F_SDY * n], F[F_SDZ * n]); ps.smaxt = F[F_SMAXT * n];
     ps.neeRaw = v3(F[F_NRX * n], F[F_NRY * n], F[F_NRZ * n]); ps.neeBeta = v3(F[F_NBX * n], F[F_NBY * n], F[F_NBZ * n]); ps.neeW = F[F_NW * n];
     ps.LiFinish = v3(F[F_LFX * n], F[F_LFY * n], F[F_LFZ * n]);
     acc = v3(F[F_ACX * n], F[F_ACY * n], F[F_ACZ * n]);
     ps.rng.v0 = U[U_R0 * n]; ps.rng.v1 = U[U_R1 * n]; ps.rng.v2 = U[U_R2 * n]; ps.rng.v3 = U[U_R3 * n]; ps.rng.v4 = U[U_R4 * n]; ps.rng.d = U[U_RD * n];
-    ps.depth = (int)U[U_DEPTH * n]; ps.guard = (int)U[U_GUARD * n]; ps.msTop = (int)U[U_MSTOP * n]; ps.flags = U[U_FLAGS * n];
+    ps.depth = (int)U[U_DEPTH * n]; ps.guard = (int)U[U_GUARD * n]; ps.flags = U[U_FLAGS * n];
     samplesLeft = (int)U[U_SAMPLES * n];
-    ms.w0 = U[U_M0 * n]; ms.w1 = U[U_M1 * n]; ms.w2 = U[U_M2 * n]; ms.w3 = U[U_M3 * n];
+    if (SIMPLE) { ps.msTop = 1; ms.w0 = ms.w1 = ms.w2 = ms.w3 = 0u; }
+    else { ps.msTop = (int)U[U_MSTOP * n]; ms.w0 = U[U_M0 * n]; ms.w1 = U[U_M1 * n]; ms.w2 = U[U_M2 * n]; ms.w3 = U[U_M3 * n]; }
 }
 
+template <bool SIMPLE = false>
 PT_DEV void wf_store(const WfParams& W, int p, const PathState& ps, const RegMedium& ms, V3 acc, int samplesLeft) {
     float* F = W.F + p; uint32_t* U = W.U + p; const size_t n = W.n;
     F[F_OX * n] = ps.o.x; F[F_OY * n] = ps.o.y; F[F_OZ * n] = ps.o.z; F[F_DX * n] = ps.d.x; F[F_DY * n] = ps.d.y; F[F_DZ * n] = ps.d.z;
     F[F_BX * n] = ps.beta.x; F[F_BY * n] = ps.beta.y; F[F_BZ * n] = ps.beta.z; F[F_LIX * n] = ps.Li.x; F[F_LIY * n] = ps.Li.y; F[F_LIZ * n] = ps.Li.z;
     F[F_PPX * n] = ps.prevPoint.x; F[F_PPY * n] = ps.prevPoint.y; F[F_PPZ * n] = ps.prevPoint.z;
     F[F_WOX * n] = ps.woLocal.x; F[F_WOY * n] = ps.woLocal.y; F[F_WOZ * n] = ps.woLocal.z;
-    F[F_PDF * n] = ps.pdf; F[F_ETAI * n] = ps.etaI; F[F_ETAT * n] = ps.etaT;
+    F[F_PDF * n] = ps.pdf;
+    if (!SIMPLE) { F[F_ETAI * n] = ps.etaI; F[F_ETAT * n] = ps.etaT; }
     F[F_SOX * n] = ps.so.x; F[F_SOY * n] = ps.so.y; F[F_SOZ * n] = ps.so.z; F[F_SDX * n] = ps.sd.x; F[F_SDY * n] = ps.sd.y; F[F_SDZ * n] = ps.sd.z; F[F_SMAXT * n] = ps.smaxt;
     F[F_NRX * n] = ps.neeRaw.x; F[F_NRY * n] = ps.neeRaw.y; F[F_NRZ * n] = ps.neeRaw.z;
     F[F_NBX * n] = ps.neeBeta.x; F[F_NBY * n] = ps.neeBeta.y; F[F_NBZ * n] = ps.neeBeta.z; F[F_NW * n] = ps.neeW;
     F[F_LFX * n] = ps.LiFinish.x; F[F_LFY * n] = ps.LiFinish.y; F[F_LFZ * n] = ps.LiFinish.z;
     F[F_ACX * n] = acc.x; F[F_ACY * n] = acc.y; F[F_ACZ * n] = acc.z;
     U[U_R0 * n] = ps.rng.v0; U[U_R1 * n] = ps.rng.v1; U[U_R2 * n] = ps.rng.v2; U[U_R3 * n] = ps.rng.v3; U[U_R4 * n] = ps.rng.v4; U[U_RD * n] = ps.rng.d;
-    U[U_DEPTH * n] = (uint32_t)ps.depth; U[U_GUARD * n] = (uint32_t)ps.guard; U[U_MSTOP * n] = (uint32_t)ps.msTop; U[U_FLAGS * n] = ps.flags;
+    U[U_DEPTH * n] = (uint32_t)ps.depth; U[U_GUARD * n] = (uint32_t)ps.guard; U[U_FLAGS * n] = ps.flags;
     U[U_SAMPLES * n] = (uint32_t)samplesLeft;
-    U[U_M0 * n] = ms.w0; U[U_M1 * n] = ms.w1; U[U_M2 * n] = ms.w2; U[U_M3 * n] = ms.w3;
+    if (!SIMPLE) { U[U_MSTOP * n] = (uint32_t)ps.msTop; U[U_M0 * n] = ms.w0; U[U_M1 * n] = ms.w1; U[U_M2 * n] = ms.w2; U[U_M3 * n] = ms.w3; }
 }
 
 // Slot p = local tile * 64 + lane, the same mapping as the megakernel's tile buffer.
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(256) wf_finish_kernel(WfParams W) {
 }
 
 // One logic step per path slot. `it` selects the queue counter pair of this iteration.
-template <int INTEG, bool COUNT>
+template <int INTEG, bool COUNT, bool SIMPLE = false>
 __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S, CamK cam, int maxDepth, int useMIS, int it) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -108,7 +114,7 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
     if (p < W.n) {
         const size_t n = W.n;
         PathState ps; RegMedium ms; V3 acc; int samplesLeft;
-        wf_load(W, p, ps, ms, acc, samplesLeft);
+        wf_load<SIMPLE>(W, p, ps, ms, acc, samplesLeft);
         const bool live = (ps.flags & (kInPath | kShadowPending)) != 0 || samplesLeft > 0;
         if (live) {
             Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
             auto noShadow = [](V3, V3, float) { return v3(1.0f); };
             apply_pending(ps, thr, acc);
             if (ps.flags & kInPath) {
-                bool done = path_bounce<INTEG, COUNT, true>(S, ps, ms, h, maxDepth, useMIS, noShadow, c);
+                bool done = path_bounce<INTEG, COUNT, true, SIMPLE>(S, ps, ms, h, maxDepth, useMIS, noShadow, c);
                 if (!done) done = path_exhausted<INTEG>(ps, maxDepth);
                 if (done) {
                     if (ps.flags & kShadowPending) { ps.LiFinish = ps.Li; ps.flags |= kFinishPending; } else acc = acc + ps.Li;
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
             }
             hasExt = (ps.flags & kInPath) != 0;
             hasShadow = (ps.flags & kShadowPending) != 0;
-            wf_store(W, p, ps, ms, acc, samplesLeft);
+            wf_store<SIMPLE>(W, p, ps, ms, acc, samplesLeft);
             if (COUNT && W.pathCtr) {
                 uint32_t* pc = W.pathCtr + p;
                 pc[0] += c.raysClosest; pc[n] += c.raysShadow; pc[2 * n] += c.pops; pc[3 * n] += c.boxes;
@@ -295,13 +301,15 @@ hipError_t launch_wf_counters(const WfParams& W, uint32_t* pixCounters, unsigned
     hipLaunchKernelGGL(wf_counters_kernel, dim3((W.n + 255) / 256), dim3(256), 0, s, W, pixCounters, totals);
     return hipGetLastError();
 }
-hipError_t launch_wf_logic(int integrator, bool count, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s) {
+hipError_t launch_wf_logic(int integrator, bool count, bool simple, const WfParams& W, const DeviceScene& S, const CamK& cam, int maxDepth, int useMIS, int it, hipStream_t s) {
     dim3 g((W.n + 255) / 256), b(256);
     if (integrator == 2) {
         if (count) hipLaunchKernelGGL((wf_logic_kernel<2, true>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
+        else if (simple) hipLaunchKernelGGL((wf_logic_kernel<2, false, true>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
         else hipLaunchKernelGGL((wf_logic_kernel<2, false>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
     } else {
         if (count) hipLaunchKernelGGL((wf_logic_kernel<0, true>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
+        else if (simple) hipLaunchKernelGGL((wf_logic_kernel<0, false, true>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
         else hipLaunchKernelGGL((wf_logic_kernel<0, false>), g, b, 0, s, W, S, cam, maxDepth, useMIS, it);
     }
     return hipGetLastError();
