@@ -43,3 +43,16 @@ def test_committed_bench_line_follows_from_committed_inputs(capsys):
     for s in b["secondary"]:
         assert s["roofline"]["bound"] == "l1_lines" and 0.0 < s["roofline"]["ta_busy_frac"] <= 1.0
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
+
+
+def test_every_committed_build_of_the_round_rendered_the_same_full_frames():
+    """bench.py hashes the timed frame (and fails if it differs from the counting kernel's frame): the full 1080p frames of the
+    three workloads are the same bits in every build whose bench line is committed — kernels, layouts and options changed, the
+    image did not."""
+    seen = {}
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r02_v*_bench.json")):
+        b = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
+        for row in [b] + b.get("secondary", []):
+            if row.get("frame_sha"):
+                seen.setdefault(row["config"]["workload"], set()).add(row["frame_sha"])
+    assert len(seen) == 3 and all(len(v) == 1 for v in seen.values()), seen
