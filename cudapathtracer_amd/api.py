@@ -109,6 +109,7 @@ def lib():
     L.pt_launch_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
     L.pt_launch_naive_unidirectional.argtypes = [i32, Camera, vp, i32, i32, i32, i32, vp]
     L.pt_set_variant.argtypes = [vp, i32]
+    L.pt_has_experimental.restype = i32
     L.pt_get_counters.argtypes = [vp, vp]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
@@ -157,6 +158,12 @@ def _p(a):
 def _check(rc, what):
     if rc != 0:
         raise PtError("%s failed (%d): %s" % (what, rc, lib().pt_last_error().decode(errors="replace")))
+
+
+def has_experimental():
+    """True if libptamd.so was built with EXPERIMENTAL=1 (the A/B variants of DESIGN.md §6: options wide, compact, spec,
+    defer_shadow, xcd_bands, refill = 2). The default library refuses those options with -3."""
+    return bool(lib().pt_has_experimental())
 
 
 def device_count():

@@ -537,7 +537,8 @@ static int render_tiles_wavefront(pt_scene* s, const pt_camera* cam, int w, int 
     return 0;
 }
 
-// The reference tree collapsed to 4-wide nodes for trace_resume_w4 (pt_trace.h): same leaves, same float boxes, half the
+#ifdef PT_EXPERIMENTAL
+// The reference tree collapsed to 4-wide nodes for trace_resume_w4 (pt_trace_experimental.h): same leaves, same float boxes, half the
 // levels. Built once per scene from the packed binary records (whoever packed them, host or device), numbered breadth-first
 // so that the first K wide nodes are the top of the tree (the LDS scene cache). A slot takes the place of an internal child
 // by that child's two children — the child with the largest box first — until the node has four slots or only leaves.
@@ -679,6 +680,7 @@ static int ensure_compact(pt_scene* s) {
     s->compactOk = true;
     return 0;
 }
+#endif  // PT_EXPERIMENTAL
 
 // rng init + megakernel on `stream`; d_tiles holds t.count*64 float4.
 static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp, int maxDepth, int integrator, int useMIS,
@@ -701,16 +703,17 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     const long long slotsHbm = (long long)s->numCU * 4 * wavesHbm;
     const bool hbm = !onchip && !deferred && s->wavesHbmOk &&
                      (s->wavesHbmForce || (simpleHbm ? (long long)t.count * 4 >= slotsHbm * 3 : (long long)t.count * 4 >= slotsHbm * 5));
-    bool wide = false;
+    bool wide = false, compact = false;
+#ifdef PT_EXPERIMENTAL
     if (hbm && simpleHbm && s->wideWanted) {
         if (int r = ensure_wide(s)) return r;
         wide = s->nWide > 0;
     }
-    bool compact = false;
     if (hbm && simpleHbm && s->compactWanted && !wide) {
         if (int r = ensure_compact(s)) return r;
         compact = s->compactOk;
     }
+#endif
     const int spillEntries = hbm ? std::max(0, (wide ? std::max(s->wideStackNeed, s->stackNeed) : s->stackNeed) - kStackLdsHbm) : s->ds.stackSpill;
     const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
@@ -890,6 +893,14 @@ int pt_render_counted(pt_scene* s, const pt_camera* cam, int w, int h, int spp, 
     return render_host(s, cam, w, h, spp, maxDepth, integrator, useMIS, seed, tiles, out, outCounters, true);
 }
 
+int pt_has_experimental(void) {
+#ifdef PT_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int pt_set_variant(pt_scene* s, int variant) {
     if (!s) return fail(-1, "null scene");
     if (variant != 0 && variant != 1) return fail(-1, "unknown variant %d (0 = megakernel, 1 = wavefront)", variant);
@@ -955,6 +966,13 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
     const int k = option_index(name);
     if (k < 0) return fail(-1, "pt_set_option: unknown option '%s'", name ? name : "(null)");
     if (v < kOptions[k].lo || v > kOptions[k].hi) return fail(-1, "pt_set_option: %s = %d is outside [%d, %d]", name, v, kOptions[k].lo, kOptions[k].hi);
+#ifndef PT_EXPERIMENTAL
+    // A/B variants that lost their measurements are not in a default build: only their "off" value is accepted.
+    {
+        const bool exp = ((k == 7 || k == 13 || k == 19 || k == 20) && v != 0) || (k == 3 && v == 2) || (k == 15 && v != 2);
+        if (exp) return fail(-3, "pt_set_option: %s = %d selects an experimental kernel; rebuild with `make EXPERIMENTAL=1` (pt_has_experimental() == 0)", name, v);
+    }
+#endif
     switch (k) {
         case 0: s->flatWanted = v; break;
         case 1: s->onchipOk = v != 0; break;

@@ -147,9 +147,13 @@ PT_DEV void megakernel_body(const KParams& P) {
     constexpr int kMedBytes = SIMPLE ? 0 : kMediumMax * 64;                 // SIMPLE kernels have no medium stack (pt_path.h)
     const int attrOff = ATTRLDS ? P.cacheNodes * 64 + P.cacheTris * 48 + nW * (STACKN * 256 + kMedBytes) : 0;
     DeviceScene Sstage = S;
+#ifdef PT_EXPERIMENTAL
     constexpr bool WIDE = TREE == 1, COMPACT = TREE == 2;
     if (WIDE) Sstage.nodes = reinterpret_cast<const PNode*>(P.wnodes);       // the LDS scene cache of the WIDE kernel holds wide nodes (P.cacheNodes counts 64-byte halves)
     if (COMPACT) Sstage.nodes = reinterpret_cast<const PNode*>(P.qnodes);    // ... of the COMPACT kernel 32-byte nodes, two per unit
+#else
+    static_assert(TREE == 0, "the wide / compact trees are -DPT_EXPERIMENTAL builds (pt_trace_experimental.h)");
+#endif
     const SceneCache SC = stage_scene_cache(Sstage, P.cacheNodes, P.cacheTris, attrOff, P.cacheAttrs, P.cacheMats, P.cacheLights);      // contains the only barrier
     if constexpr (ATTRLDS) {
         // The bounce reads its records through S; pointing S at the LDS copies makes those loads ds_reads (the address
@@ -162,17 +166,18 @@ PT_DEV void megakernel_body(const KParams& P) {
         lds_light* l = (lds_light*)(pt_smem + attrOff + P.cacheAttrs * 80 + P.cacheMats * 96);
         S.attrs = (const PAttr*)a; S.mats = (const PMat*)m; S.lights = (const PLight*)l;
     }
-    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2. Default: tile =
-    // blockIdx order, i.e. the XCDs interleave over the frame at 32x8-pixel granularity — every XCD gets
-    // the same mix of cheap and expensive regions. xcdBands (PT_XCD_BANDS=1) instead gives each XCD one
-    // contiguous band so its L2 holds only that band's geometry; measured: no gain on the 263 k scene
-    // (secondary rays leave the band at once), -14 % / -9 % on the 82 k scene / Cornell (bands differ
-    // in cost and a static 1/8 split cannot rebalance). Kept as the A/B switch.
+    // Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: with tile = blockIdx order the
+    // XCDs interleave over the frame at 32x8-pixel granularity — every XCD gets the same mix of cheap and expensive
+    // regions. (One contiguous band of tiles per XCD, so that its L2 holds only that band's geometry, measured no gain on
+    // the 263 k scene — secondary rays leave the band at once — and -14 % / -9 % on the 82 k scene / Cornell: bands differ
+    // in cost and a static 1/8 split cannot rebalance. Option "xcd_bands" of -DPT_EXPERIMENTAL builds.)
     int vb = blockIdx.x;
+#ifdef PT_EXPERIMENTAL
     if (P.xcdBands) {
         const int nB = gridDim.x, q = nB >> 3, r = nB & 7, x = vb & 7;
         vb = x * q + (x < r ? x : r) + (vb >> 3);
     }
+#endif
     // Persistent waves (P.queue != null): the grid only fills the chip and every wave takes its next tile
     // from the queue, so a wave slot is never parked behind the slowest of four sibling waves or behind
     // workgroup launch; tiles are independent, so the order does not reach the image.
@@ -225,7 +230,10 @@ PT_DEV void megakernel_body(const KParams& P) {
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
     RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
-    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.pend = kRefNone; rs.flags = 0u;
+    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
+#ifdef PT_EXPERIMENTAL
+    rs.pend = kRefNone;
+#endif
 #ifdef PT_STAMPS
     unsigned long long stamp[4] = {0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -309,6 +317,7 @@ PT_DEV void megakernel_body(const KParams& P) {
                 }
                 const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
                 if (hasExt || hasShadow) {
+#ifdef PT_EXPERIMENTAL
                     bool irregular = false;
                     if constexpr (WIDE) irregular = (hasExt && !inv_is_regular(inv3(ps.d))) || (hasShadow && !inv_is_regular(inv3(ps.sd)));
                     if (WIDE && irregular) {
@@ -320,12 +329,15 @@ PT_DEV void megakernel_body(const KParams& P) {
                         h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
                         if (hasExt) trace_closest_plain<false, STACKN, false, false>(S, none, ps.o, ps.d, 999999.0f, st, h, c);
                         rs.flags = 0u;
-                    } else ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+                    } else
+#endif
+                    ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
                 }
             }
             PT_STAMP(2);
             const int nBusy = __builtin_popcountll(__ballot((rs.flags & kRayBusy) != 0));
             if (nBusy == 0) break;
+#ifdef PT_EXPERIMENTAL
             if constexpr (COMPACT) {
                 const Compact K{P.qnodes, reinterpret_cast<const f4v*>(P.leafBox), P.mids};
                 trace_resume_q<STACKN>(S, SC, K, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, Keep{P.nodeKeep, P.triKeep});
@@ -343,7 +355,10 @@ PT_DEV void megakernel_body(const KParams& P) {
                 PT_STAMP(1);
                 continue;
             }
-#if PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
+#endif
+#if !defined(PT_EXPERIMENTAL)
+            trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+#elif PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
             if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
             else trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 1
@@ -377,7 +392,9 @@ PT_DEV void megakernel_body(const KParams& P) {
               if (hasExt && h2.tri == h.tri) h.t = fminf_(h.t, h2.t); thr.x = fminf_(thr.x, thr2.x); }
 #endif
         }
+#ifdef PT_EXPERIMENTAL
         else if (DEFER) trace_pair<COUNT, STACKN>(S, SC, st, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
+#endif
         else if constexpr (FLAT) {
             trace_closest_flat<STACKN, FLATW>(S, SC, hasExt, ps.o, ps.d, 999999.0f, st, h, c, P.cacheNodes, P.leaves, P.nLeaves);
 #ifdef PT_DIAG_DOUBLE_CLOSEST       // cost measurement only: the closest-hit traversal run twice, same result
@@ -476,15 +493,17 @@ __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
 #endif
 megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, SIMPLE, 1>(P); }
 
-// ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace.h: trace_resume_w4).
+#ifdef PT_EXPERIMENTAL
+// ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace_experimental.h: trace_resume_w4).
 template <int INTEG>
 __global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
 megakernel_hbm_wide(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, 1>(P); }
 
-// ... and on 32-byte quantised nodes with exact leaf boxes (pt_trace.h: trace_resume_q).
+// ... and on 32-byte quantised nodes with exact leaf boxes (pt_trace_experimental.h: trace_resume_q).
 template <int INTEG>
 __global__ void __launch_bounds__(64 * kWgWavesHbmSimple) __attribute__((amdgpu_waves_per_eu(kWavesHbmSimple)))
 megakernel_hbm_compact(KParams P) { megakernel_body<INTEG, false, false, false, kStackLdsHbm, false, true, false, true, 1, 2>(P); }
+#endif
 
 // The SIMPLE production kernel for scenes in HBM: 8 waves per SIMD, 16-wave workgroups (pt_params.h).
 template <int INTEG>

@@ -15,8 +15,13 @@ hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, d
         else { PT_LDS_OK((megakernel_flat2<0, false>)); hipLaunchKernelGGL((megakernel_flat2<0, false>), grid, block, lds, stream, P); }
         return hipGetLastError();
     }
-#define PT_PICK(I) do { if (P.refill) { if (count) PT_LAUNCH(I, true, true, false); else PT_LAUNCH(I, false, true, false); } \
-                        else if (P.flat == 2 && !count && P.simple) { PT_LDS_OK((megakernel<I, false, false, true, false, true, true, 2>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true, 2>), grid, block, lds, stream, P); } \
+#ifdef PT_EXPERIMENTAL      // option "refill" 2: the resumable traversal for LDS-resident scenes too (-32 % on Cornell)
+#define PT_PICK_REFILL(I) if (P.refill) { if (count) PT_LAUNCH(I, true, true, false); else PT_LAUNCH(I, false, true, false); } else
+#else
+#define PT_PICK_REFILL(I)
+#endif
+#define PT_PICK(I) do { PT_PICK_REFILL(I) \
+                        if (P.flat == 2 && !count && P.simple) { PT_LDS_OK((megakernel<I, false, false, true, false, true, true, 2>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true, 2>), grid, block, lds, stream, P); } \
                         else if (P.flat == 2 && !count) { PT_LDS_OK((megakernel<I, false, false, true, false, true, false, 2>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, false, 2>), grid, block, lds, stream, P); } \
                         else if (P.flat && !count && P.simple) { PT_LDS_OK((megakernel<I, false, false, true, false, true, true>)); hipLaunchKernelGGL((megakernel<I, false, false, true, false, true, true>), grid, block, lds, stream, P); } \
                         else if (P.flat && !count) PT_LAUNCH(I, false, false, true); \
@@ -24,6 +29,7 @@ hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, d
                         else PT_LAUNCH(I, false, false, false); } while (0)
     if (integrator == 2) PT_PICK(2); else PT_PICK(0);
 #undef PT_PICK
+#undef PT_PICK_REFILL
 #undef PT_LAUNCH
 #undef PT_LDS_OK
     return hipGetLastError();

@@ -196,8 +196,6 @@ int pt_set_culling(pt_scene* scene, int on);
  * other options choose between instantiations / schedules whose results are bit-identical (tests/test_gpu_parity.py
  * drives every one of them against the oracle). They exist for A/B measurements and for the tests.
  *   "flat" 0|1            FLAT closest-hit traversal for LDS-resident scenes of at most 128 nodes and triangles (1; 2 = 1)
- *   "wide" 0|1            SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes (0: measured 10-30 % slower)
- *   "compact" 0|1         ... or 32-byte quantised inner nodes with exact leaf boxes (0: same frames, measured 20 % slower)
  *   "wf_wide_wg" 0|1|2    wavefront variant, scenes in HBM: the trace kernel in 16-wave workgroups sharing 48 KB of the tree top (1: when
  *                         the launch has enough paths to fill them, 2: always)
  *   "leaf_boxes" 0|1      FLAT kernels test each leaf's own box instead of walking the nodes in lockstep (1)
@@ -206,19 +204,23 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
- *   "refill" 0|1|2        resumable traversal: off / scenes in HBM / also LDS-resident scenes (1)
- *   "spec" 1|2            -DPT_SPEC=1 builds only (A/B): speculative descent for closest-hit rays / shadow rays too (2)
+ *   "refill" 0|1          resumable traversal for scenes in HBM (1)
  *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (4, 10, 8)
- *   "defer_shadow" 0|1    trace shadow + extension ray as a pair in the 4-wave kernel (0)
  *   "slice_iters" n       bounce iterations a wave keeps a tile before it queues it again, 0 = until finished (512)
  *   "slice_always" 0|1    time slices from the first tile on (1)
  *   "sched_mask" 2^k-1    a wave looks at the queue every sched_mask + 1 iterations (31)
  *   "lpt_prio" 0|1|2      issue-priority steering: off / once no fresh tile is left / always (2)
  *   "persistent" 0|1      persistent waves on the tile queue (1)
- *   "xcd_bands" 0|1       one contiguous band of tiles per XCD (0)
+ * Experimental options — variants that were built, proven bit-identical and measured SLOWER. The default
+ * library does not contain their kernels (pt_has_experimental() == 0) and accepts only their "off" value, returning -3
+ * otherwise; `make -C cudapathtracer_amd/csrc EXPERIMENTAL=1` builds them for the A/B:
+ *   "wide" 0|1 (4-wide collapsed tree), "compact" 0|1 (32-byte quantised nodes), "spec" 1|2 (speculative descent, with
+ *   -DPT_SPEC=1), "defer_shadow" 0|1 (pair walk in the 4-wave kernel), "xcd_bands" 0|1 (one band of tiles per XCD),
+ *   "refill" 2 (resumable traversal for LDS-resident scenes too).
  * Returns 0, or < 0 for an unknown name / a value out of range. */
 int pt_set_option(pt_scene* scene, const char* name, int value);
 int pt_get_option(pt_scene* scene, const char* name, int* value);
+int pt_has_experimental(void);
 /* Eight more sums since the last pt_reset_counters. Normal build: out8[0] = internal-node fetches of counting launches
  * that went to global memory (node index beyond the LDS scene cache) — with tri_tests, the L1 line-access count behind
  * bench.py's roofline for scenes in HBM; the rest zero. Diagnostic builds:

@@ -208,6 +208,10 @@ def test_loop_exits_and_refill(api, gpu_ready, knobs):
     per-pixel work counters bit for bit at every threshold, on all kernels (timed and counting instantiations)."""
     opts = {k: int(v) for k, v in zip(("refill", "refill_keep", "node_keep", "tri_keep", "waves_hbm", "onchip", "slice_iters", "spec"), knobs)}
     opts["sched_mask"] = 3
+    if not api.has_experimental():                       # default library: no speculative descent, no REFILL for LDS-resident scenes
+        del opts["spec"]
+        if opts["refill"] == 2:
+            pytest.skip("refill = 2 is an EXPERIMENTAL=1 build (DESIGN.md §6)")
     used = []
     for case in CASES:
         g = np.load(os.path.join(GOLDEN, case + ".npz"))
@@ -293,7 +297,10 @@ def test_render_hand_built_deep_tree(api, oracle, gpu_ready, integrator, layout)
     one tile per wave (persistent=0) or in per-XCD bands."""
     opts = {"waves_hbm": 2}                              # the 6-wave kernel also for this 6-tile frame
     if layout == "one_tile_per_wave": opts["persistent"] = 0
-    if layout == "xcd_bands": opts["xcd_bands"] = 1
+    if layout == "xcd_bands":
+        if not api.has_experimental():
+            pytest.skip("xcd_bands is an EXPERIMENTAL=1 build (DESIGN.md §6)")
+        opts["xcd_bands"] = 1
     arr = _chain_arrays(api)
     gs, osc = api.Scene.from_arrays(arr, options=opts), oracle.OracleScene(arrays=arr)
     cam = api.Camera.Pinhole((0, 0, 1), 24, 16)
@@ -665,6 +672,14 @@ def test_options_api(api, gpu_ready):
             sc.set_option(name, bad)
     sc.set_options({"flat": 0, "sched_mask": 7, "waves_hbm": 2})
     assert (sc.get_option("flat"), sc.get_option("sched_mask"), sc.get_option("waves_hbm")) == (0, 7, 2)
+    # variants that lost their A/B are not in the default library: only their "off" value is accepted (rc -3 otherwise)
+    for name, on in (("wide", 1), ("compact", 1), ("defer_shadow", 1), ("xcd_bands", 1), ("refill", 2), ("spec", 1)):
+        if api.has_experimental():
+            sc.set_option(name, on)
+        else:
+            with pytest.raises(api.PtError, match="experimental"):
+                sc.set_option(name, on)
+        sc.set_option(name, defaults[name])
 
 
 def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
@@ -692,6 +707,8 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
     bounces, paths of up to 100 iterations) — the production kernel for scenes in HBM (12-wave workgroups, loop exits,
     REFILL; forced although a window has few tiles), the 4-wave kernel with plain loops, the counting kernel (all eight
     per-pixel counters) and the wavefront variant (C5). Committed fixture AND a live oracle run of the first window."""
+    if mode == "compact" and not api.has_experimental():
+        pytest.skip("compact nodes are an EXPERIMENTAL=1 build (DESIGN.md §6)")
     g = np.load(os.path.join(GOLDEN, case + ".npz"))
     s = window_scene(g, os.path.join(scene_dir, case))
     assert s["sha256"] == str(g["scene_sha256"])
@@ -866,8 +883,9 @@ def test_flat_leaf_boxes_and_degenerate_directions(api, oracle, gpu_ready, scene
     assert_bits_equal(gf, of, "axis-parallel rays")
 
 
-def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
-    """pt_trace.h trace_resume_w4: SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes, children in no
+def test_tie_scenes_and_axis_parallel_rays_in_hbm_kernels(api, oracle, gpu_ready, scene_dir):
+    """The production kernel for scenes in HBM on the cases built for the opt-in trees (EXPERIMENTAL=1 builds add those:
+    pt_trace_experimental.h trace_resume_w4: SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes, children in no
     particular order; equal-t ties and rays with a zero direction component fall back to the reference traversal. A scene
     whose every second quad is DOUBLED (each hit on them a two-way tie between different leaves), an axis-aligned camera
     (primary rays with exact zero components), and a blob — against the oracle. Opt-in ("wide" = 1): measured slower.
@@ -882,8 +900,11 @@ def test_wide_tree_kernel(api, oracle, gpu_ready, scene_dir):
         i = hs.info
         for cam in (hs.camera(), api.Camera.NotPinhole((0.0, 0.0, 1.0), i["width"], i["height"], (0.0, 0.0, 0.0), 60.0, 0.0, 1.0)):
             ocol, _, _ = osc.render(camera=np.frombuffer(cam.tobytes(), np.uint8), threads=8)
-            for opts in ({"onchip": 0, "waves_hbm": 2, "wide": 1}, {"onchip": 0, "waves_hbm": 2}, {"onchip": 0, "waves_hbm": 2, "wide": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12},
-                         {"onchip": 0, "waves_hbm": 2, "compact": 1}, {"onchip": 0, "waves_hbm": 2, "compact": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12}):
+            variants = ({"onchip": 0, "waves_hbm": 2}, {"onchip": 0, "waves_hbm": 2, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12})
+            if api.has_experimental():
+                variants += ({"onchip": 0, "waves_hbm": 2, "wide": 1}, {"onchip": 0, "waves_hbm": 2, "wide": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12},
+                             {"onchip": 0, "waves_hbm": 2, "compact": 1}, {"onchip": 0, "waves_hbm": 2, "compact": 1, "slice_iters": 8, "sched_mask": 3, "refill_keep": 12})
+            for opts in variants:
                 sc = api.Scene(hs, options=opts)
                 col, _ = sc.render(cam, i["width"], i["height"], i["spp"], i["max_depth"])
                 fl = sc.flags()
