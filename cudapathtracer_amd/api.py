@@ -445,7 +445,7 @@ class Scene:
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64), "simple": bool(f & 128), "flat_pair": bool(f & 256)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64), "simple": bool(f & 128), "flat_pair": bool(f & 256), "leaf_table": bool(f & 512)}
 
     def last_kernel_ms(self):
         """Device time of the last launch; raises if that launch did not finish its frame (tile-queue timeout).

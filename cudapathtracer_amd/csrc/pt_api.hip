@@ -81,7 +81,8 @@ struct pt_scene {
     bool noLeafTris = false;                      // no triangle carries a MAT_LEAF material: a shadow ray is occluded by any hit (order-free)
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 (or 2) on: scenes of at most 128 nodes / triangles (64- or 128-bit masks)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
-    int lastLaunchFlat = 0, lastLaunchSimple = 0;
+    int lastLaunchFlat = 0, lastLaunchSimple = 0, lastLaunchLeafTable = 0;
+    bool lastLaunchQueued = false;        // the last megakernel launch used the tile queue (only then is its error word that launch's)
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // "waves_hbm" 2: ... and the 6-wave kernel whatever the tile count (tests)
@@ -141,6 +142,30 @@ static int upload(DevBuf& b, const void* src, size_t bytes) {
     if (int r = b.ensure(std::max<size_t>(bytes, 16))) return r;
     if (bytes) HIP_OK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
     return 0;
+}
+
+// The leaf table of the FLAT kernels (and the opt-in trees of EXPERIMENTAL builds) replace the reference's root-to-leaf box
+// walk by a test of each leaf's OWN box. That equals the reference's visiting set only if every box contains the boxes
+// below it and no box holds a NaN or an infinity (pt_trace.h: inv_is_regular and the monotonicity argument above it). The
+// reference's builder nests exactly (a parent's box is the float-wise min / max of its children's, main.cu:20-233), but
+// pt_scene_create also takes a caller's own BVH arrays — a refit, loose or corrupt tree must fall back to the walk that
+// tests the boxes the caller gave. pn: packed internal nodes, children numbered after their parents.
+static bool boxes_nested_and_finite(const std::vector<PNode>& pn, int nInternal) {
+    for (int i = 0; i < nInternal; i++) {
+        const PNode& p = pn[i];
+        for (int a = 0; a < 3; a++)
+            if (!(std::isfinite(p.lmin[a]) && std::isfinite(p.lmax[a]) && std::isfinite(p.rmin[a]) && std::isfinite(p.rmax[a]))) return false;
+        const int32_t ref[2] = {p.left, p.right};
+        for (int k = 0; k < 2; k++) {
+            if (ref[k] < 0) continue;                              // a leaf child: its box IS the one the table tests
+            if (ref[k] <= i || ref[k] >= nInternal) return false;
+            const PNode& c = pn[ref[k]];
+            const float* mn = k == 0 ? p.lmin : p.rmin; const float* mx = k == 0 ? p.lmax : p.rmax;
+            for (int a = 0; a < 3; a++)
+                if (!(mn[a] <= c.lmin[a] && mn[a] <= c.rmin[a] && mx[a] >= c.lmax[a] && mx[a] >= c.rmax[a])) return false;
+        }
+    }
+    return true;
 }
 
 // Re-pack the reference's data model for gfx950.
@@ -390,7 +415,7 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         if (ok && nInternal > 0) HIP_OK(hipMemcpy(s->nodes.p, pn.data(), (size_t)nInternal * sizeof(PNode), hipMemcpyHostToDevice));
         s->flatOk = ok;
         s->nLeaves = 0;
-        if (ok && nInternal > 0) {                              // the leaf table: every leaf child's box and triangle range
+        if (ok && nInternal > 0 && boxes_nested_and_finite(pn, nInternal)) {     // the leaf table: every leaf child's box and triangle range
             std::vector<PLeaf> lf;
             for (int i = 0; i < nInternal; i++) {
                 const int32_t* ref = &pn[i].left;
@@ -549,6 +574,7 @@ static int ensure_wide(pt_scene* s) {
     if (nI <= 0 || s->ds.rootRef != 0) return 0;
     std::vector<PNode> pn((size_t)nI);
     HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nI * sizeof(PNode), hipMemcpyDeviceToHost));
+    if (!boxes_nested_and_finite(pn, nI)) return 0;                    // a caller's loose tree: the reference's walk (nWide stays 0)
     struct Slot { float mn[3], mx[3]; int32_t ref; };
     auto area = [](const Slot& b) { const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
     auto children = [&](int32_t node, Slot out[2]) {
@@ -609,6 +635,7 @@ static int ensure_compact(pt_scene* s) {
     if (nI <= 0 || s->ds.rootRef != 0 || nI >= (1 << 24) || nT >= (1 << 24)) return 0;
     std::vector<PNode> pn((size_t)nI);
     HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nI * sizeof(PNode), hipMemcpyDeviceToHost));
+    if (!boxes_nested_and_finite(pn, nI)) return 0;                    // a caller's loose tree: the reference's walk (compactOk stays false)
     std::vector<QNode> qn((size_t)nI);
     std::vector<float> lb((size_t)nT * 8, 0.0f);                   // two 16-byte halves per packed triangle index; filled at the first of each leaf
     std::vector<int32_t> mids((size_t)nI, 0), minFirst((size_t)nI, 0), maxFirst((size_t)nI, 0);
@@ -758,6 +785,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
     s->lastLaunchFlat2 = (P.flat == 3) ? 1 : 0;
+    s->lastLaunchLeafTable = (P.flat && !count && P.nLeaves > 0) ? 1 : 0;
     s->lastLaunchHbm = hbm ? 1 : 0;
     P.onchip = onchip ? 1 : 0;
     P.wavesPerSimd = hbm ? wavesHbm : (PT_MIN_WAVES > 0 ? PT_MIN_WAVES : 4);
@@ -772,6 +800,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         P.queue = (int*)s->queue.p; P.queueMask = cap - 1; P.left = (int*)s->left.p;
         P.gridBlocks = s->numCU * P.wavesPerSimd * 4 / wgWaves;      // n waves per SIMD = 4n waves per CU, in workgroups of wgWaves
     }
+    s->lastLaunchQueued = P.queue != nullptr;
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = spillEntries > 0 ? (int32_t*)s->spill.p : nullptr;
@@ -929,7 +958,7 @@ int pt_debug_stamps(pt_scene* s, unsigned long long* out8) {
 // The tile queue's waits are bounded (pt_kernels.hip); a wait that ran out leaves q[3] != 0 and an
 // unfinished frame. Read where the host waits for the kernel anyway.
 static int queue_error(pt_scene* s) {
-    if (!s->queue.p || s->variant != 0) return 0;
+    if (!s->queue.p || s->variant != 0 || !s->lastLaunchQueued) return 0;     // (an error word left by an earlier queued launch is not this launch's)
     int q[4] = {0, 0, 0, 0};
     if (hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess) return fail(-2, "tile queue read-back failed");
     if (q[3] != 0) return fail(-4, "megakernel tile queue timed out (code %d, %d tiles finished): the frame is incomplete", q[3], q[2]);
@@ -1036,7 +1065,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0) | (s->lastLaunchFlat2 ? 256 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0) | (s->lastLaunchFlat2 ? 256 : 0) | (s->lastLaunchLeafTable ? 512 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

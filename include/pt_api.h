@@ -182,7 +182,9 @@ float pt_last_kernel_ms(pt_scene* scene);
  * instantiation (scenes in HBM: finished lanes shade and return while the others keep tracing), bit 6 = it used the FLAT
  * closest-hit traversal (LDS-resident scenes with at most 64 nodes and triangles), bit 7 = it used the SIMPLE bounce
  * (every triangle an untextured MAT_DIFFUSE: one arm per dispatcher, no medium stack), bit 8 = the pair form of FLAT
- * (shadow + extension ray in one pass). For labelling measurements. */
+ * (shadow + extension ray in one pass), bit 9 = the FLAT launch decided the visited leaves from the leaves' own boxes (the
+ * scene's boxes are finite and nested, checked at pt_scene_create; a caller's loose or refit tree takes the lockstep walk
+ * over the boxes as given). For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a

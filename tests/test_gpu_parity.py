@@ -883,6 +883,47 @@ def test_flat_leaf_boxes_and_degenerate_directions(api, oracle, gpu_ready, scene
     assert_bits_equal(gf, of, "axis-parallel rays")
 
 
+def test_caller_tree_with_loose_boxes_takes_the_reference_walk(api, oracle, gpu_ready):
+    """pt_scene_create also takes a caller's own BVH arrays (array-level boundary, main.cu:469-557). visited(leaf) ==
+    slab(leaf's own box) holds only for finite, nested boxes; a tree whose inner box does NOT contain its children (a refit
+    gone wrong, here: an internal node's box shrunk to a quarter) must render as the reference's walk over the boxes as
+    given — the FLAT kernels fall back to the lockstep node walk (flag leaf_table off), bit for bit the oracle's frame."""
+    hs = api.HostScene(golden_scene("cornell32"))
+    names = ("points", "normals", "uvs", "mesh", "lights", "bvh", "indices", "materials")
+    arr = {k: hs.array(k) for k in names}
+    cam = hs.camera()
+    cb = np.frombuffer(cam.tobytes(), np.uint8)
+    nested = api.Scene.from_arrays(arr)
+    nested.render(cam, 32, 32, 1, 4)
+    assert nested.flags()["flat"] and nested.flags()["leaf_table"], nested.flags()
+    bvh = arr["bvh"].view(np.float32).reshape(-1, 12).copy()
+    bi = bvh.view(np.int32)
+    inner = [i for i in range(1, len(bvh)) if bi[i, 11] <= 0]                # internal nodes below the root
+    assert len(inner) >= 3
+    differs = 0
+    for victim, how in ((inner[0], "shrunk"), (inner[len(inner) // 2], "shrunk"), (inner[-1], "infinite")):
+        b = bvh.copy()
+        if how == "shrunk":
+            c, e = 0.5 * (b[victim, 0:3] + b[victim, 4:7]), 0.5 * (b[victim, 4:7] - b[victim, 0:3])
+            b[victim, 0:3], b[victim, 4:7] = c - 0.25 * e, c + 0.25 * e
+        else:
+            b[victim, 4] = np.inf                                             # still contains its children, but is not finite
+        loose = dict(arr, bvh=b.view(np.uint8).reshape(-1))
+        osc = oracle.OracleScene(arrays=loose)
+        for integ in (0, 2):
+            ocol, _, _ = osc.render(camera=cb, width=32, height=32, spp=4, max_depth=4, integrator=integ, threads=8)
+            for opts in ({}, {"flat2": 0}, {"flat": 0}):
+                sc = api.Scene.from_arrays(loose, options=opts)
+                col, _ = sc.render(cam, 32, 32, 4, 4, integrator=integ)
+                fl = sc.flags()
+                assert fl["flat"] == (opts.get("flat", 1) == 1) and not fl["leaf_table"], (victim, how, opts, fl)
+                assert_bits_equal(col, ocol, "loose tree: node %d %s, integrator %d, %s" % (victim, how, integ, opts))
+            if how == "shrunk":
+                good, _ = nested.render(cam, 32, 32, 4, 4, integrator=integ)
+                differs += int(not np.array_equal(good.view(np.uint32), ocol.view(np.uint32)))
+    assert differs >= 1          # the shrunk boxes really hide geometry: the leaf table would have rendered a different frame
+
+
 def test_tie_scenes_and_axis_parallel_rays_in_hbm_kernels(api, oracle, gpu_ready, scene_dir):
     """The production kernel for scenes in HBM on the cases built for the opt-in trees (EXPERIMENTAL=1 builds add those:
     pt_trace_experimental.h trace_resume_w4: SIMPLE scenes in HBM traverse the reference tree collapsed to 4-wide nodes, children in no
