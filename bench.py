@@ -17,9 +17,16 @@ the counted frame bit for bit (`frame_sha`; the run fails otherwise). `roofline`
 megakernel against the bound that binds it (tools/roofline.py): VALU issue slots for scenes that
 live in LDS (the headline), the L1's cache-line rate for scenes in HBM — both fractions are <= 1 by
 construction; SURVEY.md §8(d)'s algorithmic bytes are kept as the labelled field `algorithmic`.
-`secondary` (N = 1) holds the same measurement for BASELINE C3 at its full sample count and for the
-C4 scene at 32 of its 4096 spp (one timed step each). `cpu_baseline` is the CPU oracle on a bounded
-sample of the headline workload (rank 0, N = 1 only) — a reported reference point, not the target.
+`secondary` (N = 1; one timed step each, labelled) holds the same measurement for BASELINE C3 at its full
+sample count, the C4 scene at 32 of its 4096 spp, the GENERAL bounce — a 1080p Cornell box with mirror,
+glass, nested water and a GGX box (reflectors.cuh:588-629 dispatch, medium stack deviceCode.cu:347-432)
+and the 82 k-triangle scene with a glass blob — and C5, the wavefront variant on the C4 scene.
+`projected_scaling` (N = 1) is kernel time of the full frame / kernel time of rank 0's 1/N share on this
+one GPU: what N GPUs could reach before the gather — a projection, not a scaling curve.
+Counters from a PMC pass are only used if `code_sha256` of their entry in profiles/roofline_inputs.json
+equals the hash of the kernel in the library being timed; otherwise `frac` is null and `stale_profile`
+true. `cpu_baseline` is the CPU oracle on a bounded sample of the headline workload (rank 0, N = 1 only)
+— a reported reference point, not the target.
 """
 import argparse
 import json
@@ -45,7 +52,12 @@ WORKLOADS = {
     "cornell_1920x1080_1024spp_depth8_mis": ("cornell", dict(width=1920, height=1080, spp=1024, max_depth=8)),
     "blob82k_1920x1080_1024spp_depth8_mis": ("blob_in_box", dict(width=1920, height=1080, spp=1024, max_depth=8)),
     "atrium262k_1920x1080_4096spp_depth16_mis": ("atrium", dict(width=1920, height=1080, spp=4096, max_depth=16)),
+    # the general bounce: mirror tall box, glass short box with a water box nested inside, a gold (GGX) box
+    "cornell_mixed_1920x1080_1024spp_depth8_mis": ("cornell", dict(width=1920, height=1080, spp=1024, max_depth=8, tall_material=19, short_material=5,
+                                                                  nested=True, extra_boxes=1, extra_materials=[4], name="cornell_mixed")),
+    "blob82k_glass_1920x1080_1024spp_depth8_mis": ("blob_in_box", dict(width=1920, height=1080, spp=1024, max_depth=8, material=5, name="blob_glass")),
 }
+_SCENES = {}                                   # generated scenes of this process, by workload
 
 
 def host_threads():
@@ -88,6 +100,8 @@ def kernel_name(flags, variant):
         if flags.get("simple"):
             return "pt::megakernel_hbm_simple<0>"
         return "pt::megakernel_hbm<0, false, %s, %s, false>" % (_tf(flags["culling"]), _tf(flags["refill"]))
+    if flags.get("simple") and not flags["onchip"]:
+        return "pt::megakernel<0, false, false, false, true, false, true, 1>"              # small shares of a diffuse-only scene in HBM
     if flags.get("flat_pair"):
         return "pt::megakernel_flat2<0, %s>" % _tf(flags.get("simple", False))
     if flags.get("simple"):
@@ -101,9 +115,11 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
     from cudapathtracer_amd import distributed as D
     rank, world, red_dev, share = ctx["rank"], ctx["world"], ctx["red_dev"], ctx["share"]
     gen, kw = WORKLOADS[workload]
-    tmp = tempfile.mkdtemp(prefix="ptbench_r%d_" % rank)
-    sinfo = getattr(scenes, gen)(tmp, **kw)
-    host = api.HostScene(sinfo["config"])
+    if workload not in _SCENES:
+        tmp = tempfile.mkdtemp(prefix="ptbench_r%d_" % rank)
+        sinfo = getattr(scenes, gen)(tmp, **kw)
+        _SCENES[workload] = (sinfo, api.HostScene(sinfo["config"]))
+    sinfo, host = _SCENES[workload]
     info = host.info
     w, h, md = info["width"], info["height"], info["max_depth"]
     spp = spp_override or info["spp"]
@@ -167,6 +183,7 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
     elapsed, _ = et.tolist()
     if rank != 0:
+        scene.close()
         return None, None, None
     if sha_timed != sha_counted:
         raise SystemExit("bench.py: the timed frame differs from the counted frame (%s vs %s) on %s" % (sha_timed, sha_counted, workload))
@@ -178,20 +195,31 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
     # roofline of the dominant kernel (the megakernel) on THIS rank: what it did / its duration
     own_bytes = RF.alg_bytes(cnt, tr.count * 64)
     entry = RF.find_entry(RF.load_inputs(), workload, spp, kname) if (world == 1 and variant == "megakernel") else None
-    if variant == "megakernel" and not flags["onchip"]:
-        rf = RF.l1_roofline(gnodes, cnt["tri_tests"], kernel_ms)
+    # counters of a PMC pass describe the code they were measured on: use them only if the library being timed holds that very code
+    stale = entry is not None and not RF.profile_is_current(entry, ctx["code_hashes"])
+    if stale:
+        entry = None
+    if variant != "megakernel":
+        rf = {"bound": "l1_lines", "achieved": None, "peak": RF.PEAK_L1_LINES / 1e9, "unit": "Gline-access/s", "frac": None,
+              "note": "A/B variant: ~200 launches per frame, no single dominant launch; see value / ms_per_step against the megakernel's"}
+    elif not flags["onchip"]:
+        busy = RF.ta_busy(entry)                                 # from the committed PMC pass of this workload: how busy the unit behind this bound was
+        rf = {"ta_busy_frac": busy}                              # leads the block: the independent evidence that the unit behind the bound is saturated
+        rf.update(RF.l1_roofline(gnodes, cnt["tri_tests"], kernel_ms))
+        rf["peak_source"] = "micro-benchmark tools/ta_rate/quad_fetch.hip (one cache-line access per CU per clock), not a figure of MI355X_MICROARCH.md"
         rf["global_node_fetches_per_launch"] = gnodes
         rf["global_tri_tests_per_launch"] = cnt["tri_tests"]
-        busy = RF.ta_busy(entry)                                 # from the committed PMC pass of this workload: how busy the unit behind this bound was
-        if busy is not None:
-            rf["ta_busy_frac"] = busy
+        if entry is not None:
             rf["profile"] = {"file": "profiles/roofline_inputs.json", "workload": workload, "spp": spp, "source": entry.get("source")}
     else:
         rf = RF.valu_roofline(entry, kernel_ms)
-        if rf is None:                                           # no PMC pass of this exact workload / kernel is committed
+        if rf is None:                                           # no PMC pass of this exact workload / kernel / code is committed
             rf = {"bound": "valu", "achieved": None, "peak": RF.PEAK_VALU / 1e9, "unit": "Gwave-instr/s", "frac": None}
         else:
             rf["profile"] = {"file": "profiles/roofline_inputs.json", "workload": workload, "spp": spp, "source": entry.get("source")}
+    if stale:
+        rf["stale_profile"] = True                               # a PMC pass exists, but of other code: re-run tools/profile_round.sh
+    rf["code_sha256"] = ctx["code_hashes"].get(kname)
     rf["traffic"] = RF.traffic_bytes(entry)
     rf["kernel"] = kname
     rf["kernel_ms"] = kernel_ms
@@ -210,6 +238,16 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
         "frame_sha": sha_timed, "frame_equals_counted_frame": True,
         "roofline": rf,
     }
+    if ctx.get("project_shares") and world == 1 and variant == "megakernel":
+        # what N GPUs could reach on this frame before the gather: kernel time of the full frame / kernel time of rank 0's 1/N share
+        proj = {}
+        for n in (2, 4, 8):
+            trn = api.rank_tiles(w, h, 0, n)
+            tiles.zero_()
+            scene.render_tiles_device(cam, w, h, spp, md, tiles.data_ptr(), tiles=trn, stream=stream)
+            torch.cuda.synchronize()
+            proj[str(n)] = kernel_ms / scene.last_kernel_ms()
+        out["projected_scaling"] = dict(proj, note="one-GPU share measurements (kernel only, no gather): a projection, not a scaling curve")
     scene.close()
     return out, sinfo, info
 
@@ -254,17 +292,23 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     from cudapathtracer_amd import api
-    ctx = {"rank": rank, "world": world, "red_dev": red_dev, "share": share}
+    ctx = {"rank": rank, "world": world, "red_dev": red_dev, "share": share, "code_hashes": RF.kernel_code_hashes(api.LIB_PATH)}
     opts = api.parse_options(args.opt)
+    ctx["project_shares"] = world == 1 and not args.opt and not args.culling and not args.no_secondary
     out, sinfo, info = measure(ctx, args.workload, args.spp, args.steps, args.warmup, opts, args.variant, args.culling)
+    ctx["project_shares"] = False
 
     plain = world == 1 and not args.spp and not args.opt and not args.culling and args.variant == "megakernel"
     if rank == 0 and plain and not args.no_secondary and args.workload == "cornell_1920x1080_1024spp_depth8_mis":
-        # Driver-visible numbers for the kernel that serves scenes in HBM (BASELINE C3 at its full 1024 spp; the C4 / C5
-        # scene at 32 of its 4096 spp, depth 16): one counted + one timed step each, labelled.
+        # Driver-visible numbers beyond the headline, one counted + one timed step each, labelled: the kernel that serves
+        # scenes in HBM (BASELINE C3 at its full 1024 spp; the C4 / C5 scene at 32 of its 4096 spp, depth 16), the GENERAL
+        # bounce (material dispatch, medium stack, dielectric / GGX / mirror arms) on an LDS-resident scene at the headline's
+        # size and on the 82 k-triangle scene, and C5: the wavefront variant on the C4 scene.
         sec = []
-        for wl, spp in (("blob82k_1920x1080_1024spp_depth8_mis", 0), ("atrium262k_1920x1080_4096spp_depth16_mis", 32)):
-            r, _, _ = measure(ctx, wl, spp, 1, 1, {}, "megakernel", False)
+        for wl, spp, variant in (("blob82k_1920x1080_1024spp_depth8_mis", 0, "megakernel"), ("atrium262k_1920x1080_4096spp_depth16_mis", 32, "megakernel"),
+                                 ("cornell_mixed_1920x1080_1024spp_depth8_mis", 0, "megakernel"), ("blob82k_glass_1920x1080_1024spp_depth8_mis", 128, "megakernel"),
+                                 ("atrium262k_1920x1080_4096spp_depth16_mis", 32, "wavefront")):
+            r, _, _ = measure(ctx, wl, spp, 1, 1, {}, variant, False)
             sec.append({k: r[k] for k in ("value", "unit", "msample_per_s", "steps", "ms_per_step", "config", "frame_sha", "frame_equals_counted_frame", "roofline")})
         out["secondary"] = sec
     if rank == 0:

@@ -127,6 +127,7 @@ def lib():
     L.pt_render_multi.argtypes = [C.POINTER(SceneDesc), i32, vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, u64, vp, vp]
     L.pt_probe_rng.argtypes = [u64, i32, vp, i32, vp, vp, vp]
     L.pt_probe_math.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    L.pt_probe_rcp_exhaustive.argtypes = [vp, vp]
     L.pt_probe_camera_rays.argtypes = [C.POINTER(Camera), u64, i32, vp, vp]
     L.pt_probe_trace_closest.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pt_probe_trace_shadow.argtypes = [vp, i32, vp, vp, vp, vp]
@@ -586,6 +587,14 @@ def probe_math(x):
     outs = [np.zeros_like(x) for _ in range(5)]
     _check(lib().pt_probe_math(x.size, _p(x), *[_p(o) for o in outs]), "pt_probe_math")
     return dict(zip(("sin", "cos", "exp", "rsqrt", "pow5"), outs))
+
+
+def probe_rcp_exhaustive():
+    """pt_probe_rcp_exhaustive: {mismatches, in_fast_range, bare_sequence_wrong_outside_range, first_bad} over all 2^32 inputs."""
+    out = np.zeros(3, np.uint64)
+    first = np.zeros(1, np.uint32)
+    _check(lib().pt_probe_rcp_exhaustive(_p(out), _p(first)), "pt_probe_rcp_exhaustive")
+    return {"mismatches": int(out[0]), "in_fast_range": int(out[1]), "bare_wrong_outside": int(out[2]), "first_bad": int(first[0])}
 
 
 def probe_camera_rays(camera, xy, seed=SEED):

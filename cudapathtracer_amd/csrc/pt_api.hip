@@ -763,6 +763,15 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (onchip && kAttrCacheBytes > 0 && s->flatOk && s->leafBoxes && s->nLeaves > 0) { P.nLeaves = s->nLeaves; P.leaves = (const PLeaf*)s->leaves.p; }
     P.wgWaves = wgWaves;
     if (hbm && s->cacheTris == 0) P.cacheNodes = std::min(s->nInternal, (simpleHbm ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64);     // its workgroups share a larger copy of the top of the tree
+    P.gnodeFrom = P.cacheNodes;
+    if (count && !onchip && !deferred && s->wavesHbmOk) {
+        // a counting launch stands in for the timed launch of the same tiles (bench.py): count a node fetch as "global" against THAT
+        // instantiation's LDS copy of the tree top — the SIMPLE production kernel holds 768 nodes, this counting kernel 704 (or 192)
+        const bool simpleTimed = s->simpleOk && s->simpleWanted && s->refill && !s->cull && !s->armless;
+        const long long slotsTimed = (long long)s->numCU * 4 * (simpleTimed ? kWavesHbmSimple : kWavesHbm);
+        const bool hbmTimed = s->wavesHbmForce || (simpleTimed ? (long long)t.count * 4 >= slotsTimed * 3 : (long long)t.count * 4 >= slotsTimed * 5);
+        if (s->cacheTris == 0) P.gnodeFrom = hbmTimed ? std::min(s->nInternal, (simpleTimed ? kCacheBytesHbmSimple : kCacheBytesHbm) / 64) : s->cacheNodes;
+    }
     P.wide = wide ? 1 : 0; P.wnodes = wide ? (const WNode*)s->wnodes.p : nullptr;
     if (wide) P.cacheNodes = 2 * std::min(s->nWide, kCacheBytesHbmSimple / 128);            // wide nodes, counted in 64-byte halves
     P.compact = compact ? 1 : 0;
@@ -1142,6 +1151,21 @@ int pt_probe_math(int n, const float* x, float* oSin, float* oCos, float* oExp, 
     HIP_OK(launch_probe_math(n, dx, d[0], d[1], d[2], d[3], d[4], nullptr));
     HIP_OK(hipDeviceSynchronize());
     for (int k = 0; k < 5; k++) if (outs[k]) HIP_OK(hipMemcpy(outs[k], d[k], (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int pt_probe_rcp_exhaustive(unsigned long long* out3, uint32_t* first_bad) {
+    if (!out3) return fail(-1, "bad arguments");
+    Scratch sc;
+    SCRATCH(dout, unsigned long long, 32, nullptr);
+    SCRATCH(dfb, uint32_t, 16, nullptr);
+    HIP_OK(hipMemset(dout, 0, 32));
+    HIP_OK(hipMemset(dfb, 0xff, 16));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(launch_probe_rcp_exhaustive(dout, dfb, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out3, dout, 24, hipMemcpyDeviceToHost));
+    if (first_bad) HIP_OK(hipMemcpy(first_bad, dfb, 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

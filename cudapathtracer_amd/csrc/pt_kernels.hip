@@ -115,6 +115,35 @@ __global__ void probe_math_kernel(int n, const float* x, float* s, float* cth, f
     s[i] = sn; cth[i] = cs; e[i] = exp_(x[i]); rs[i] = rsqrt_(x[i]); p5[i] = pow5_(x[i]);
 }
 
+// Every binary32 bit pattern through rcp_exact (pt_device.h) against the IEEE division sequence it replaces in
+// triangleIntersect's `f = 1.0 / a` (integratorUtilities.cuh:22), in aabbIntersect's 1 / dir (:50-55) and in normalize's
+// rsqrtf (util.cuh:129). rcp_exact's fast arm is v_rcp_f32 + one Newton step; that it equals the correctly rounded quotient
+// for 1e-12 <= |a| <= 1e30 is a property of THIS GPU's v_rcp_f32 table, so every box that renders re-proves it (tests, -m gpu).
+// out[0]: inputs where rcp_exact(a) differs from 1.0f / a (the contract: 0), out[1]: inputs inside the fast arm's range,
+// out[2]: inputs OUTSIDE that range where the bare v_rcp + Newton sequence would differ (why the range guard exists; > 0).
+__global__ void __launch_bounds__(256) probe_rcp_exhaustive_kernel(unsigned long long* out, uint32_t* firstBad) {
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, inRange = 0, badOutside = 0;
+    for (unsigned long long i = i0; i < (1ull << 32); i += stride) {
+        const uint32_t u = (uint32_t)i;
+        const float a = __builtin_bit_cast(float, u);
+        const float ref = 1.0f / a;                                   // v_div_scale / v_div_fmas / v_div_fixup: correctly rounded, denormals kept
+        const float got = rcp_exact(a);
+        const uint32_t rb = __builtin_bit_cast(uint32_t, ref), gb = __builtin_bit_cast(uint32_t, got);
+        const bool same = rb == gb || (ref != ref && got != got);
+        if (!same) { bad++; atomicMin(firstBad, u); }
+        const float m = __builtin_fabsf(a);
+        if (m >= 1e-12f && m <= 1.0e30f) inRange++;
+        else {
+            const float r0 = __builtin_amdgcn_rcpf(a);
+            const float bare = __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);
+            if (!(__builtin_bit_cast(uint32_t, bare) == rb || (bare != bare && ref != ref))) badOutside++;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { bad += __shfl_down(bad, off, 64); inRange += __shfl_down(inRange, off, 64); badOutside += __shfl_down(badOutside, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], bad); atomicAdd(&out[1], inRange); atomicAdd(&out[2], badOutside); }
+}
+
 __global__ void probe_camera_kernel(const uint32_t* __restrict__ state6, CamK cam, int n, const int* xy, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -243,6 +272,10 @@ hipError_t launch_probe_rng(const uint32_t* jump, unsigned long long seed, int n
 hipError_t launch_probe_math(int n, const float* x, float* s, float* c, float* e, float* rs, float* p5, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(probe_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, s, c, e, rs, p5);
+    return hipGetLastError();
+}
+hipError_t launch_probe_rcp_exhaustive(unsigned long long* out3, uint32_t* firstBad, hipStream_t stream) {
+    hipLaunchKernelGGL(probe_rcp_exhaustive_kernel, dim3(8192), dim3(256), 0, stream, out3, firstBad);
     return hipGetLastError();
 }
 hipError_t launch_probe_camera(const uint32_t* state6, const CamK& cam, int n, const int* xy, float* out, hipStream_t stream) {

@@ -226,6 +226,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     }
     V3 acc = v3(acc4.x, acc4.y, acc4.z);
     Ctr c = {};
+    c.gnodeFrom = (uint32_t)P.gnodeFrom;
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);

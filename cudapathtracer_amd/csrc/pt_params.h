@@ -65,6 +65,7 @@ struct KParams {
     const WNode* wnodes;
     int compact;                   // 1: megakernel_hbm_compact — the SIMPLE kernel for scenes in HBM on 32-byte quantised nodes (pt_trace.h: trace_resume_q)
     const QNode* qnodes; const void* leafBox; const int32_t* mids;
+    int gnodeFrom;                 // counting launches: node indices from here on count as global fetches — the scene-cache extent of the TIMED instantiation for this launch
     int nLeaves;                   // FLAT kernels: PLeaf records in global memory, read through the scalar cache (0 = none: the lockstep node walk)
     const PLeaf* leaves;
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
@@ -148,6 +149,7 @@ hipError_t launch_probe_rng(const uint32_t* jump, unsigned long long seed, int n
                             uint32_t* outState, uint32_t* outU32, float* outUni, hipStream_t stream);
 hipError_t launch_probe_math(int n, const float* x, float* s, float* c, float* e, float* rs, float* p5, hipStream_t stream);
 hipError_t launch_probe_camera(const uint32_t* state6, const CamK& cam, int n, const int* xy, float* out, hipStream_t stream);
+hipError_t launch_probe_rcp_exhaustive(unsigned long long* out3, uint32_t* firstBad, hipStream_t stream);
 hipError_t launch_probe_closest(const DeviceScene& S, int n, const float* rays, int32_t* outI, float* outF,
                                 unsigned long long* totals, int32_t* spill, hipStream_t stream);
 hipError_t launch_probe_shadow(const DeviceScene& S, int n, const float* rays, const float* maxT, float* outF,

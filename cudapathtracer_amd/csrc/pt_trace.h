@@ -25,7 +25,8 @@ namespace pt {
 
 struct Ctr {
     uint32_t raysClosest, raysShadow, pops, boxes, tris, hits, draws, iters;
-    uint32_t gnodes;    // internal-node fetches that went to global memory (index beyond the LDS scene cache): the L1 line-rate roofline of bench.py
+    uint32_t gnodes;    // internal-node fetches a TIMED launch of the same tiles serves from global memory (index >= gnodeFrom): the L1 line-rate roofline of bench.py
+    uint32_t gnodeFrom; // ... = the LDS scene-cache extent of the instantiation that launch would run (KParams::gnodeFrom; the counting kernel's own cache is smaller)
 #ifdef PT_UTIL
     uint32_t u[8];      // diagnostic build (tools/lane_util.py): {wave-level, lane-level} steps of the node / triangle loops, closest then shadow
 #endif
@@ -215,7 +216,7 @@ PT_DEV int lanes_here() { return __builtin_popcountll(__builtin_amdgcn_ballot_w6
 template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
 PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c, float cullT = 0.0f) {
     NodeData n = load_node<ONCHIP>(S, C, cur);
-    if (COUNT) { c.pops++; c.boxes += 2; if (!ONCHIP && cur >= C.nNodes) c.gnodes++; }
+    if (COUNT) { c.pops++; c.boxes += 2; if (!ONCHIP && (uint32_t)cur >= c.gnodeFrom) c.gnodes++; }
     float tL, tR;
     bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
     bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);

@@ -266,6 +266,12 @@ int pt_render_multi(const pt_scene_desc* desc, int n_devices, const int* device_
 /* ---- probes: single stages of the path on the GPU, for known-answer tests -------------- */
 int pt_probe_rng(uint64_t seed, int n, const uint32_t* subsequences, int n_draws, uint32_t* out_state6, uint32_t* out_u32, float* out_uniform);
 int pt_probe_math(int n, const float* x, float* out_sin, float* out_cos, float* out_exp, float* out_rsqrt, float* out_pow5);
+/* All 2^32 binary32 inputs through the kernels' exact fast reciprocal (v_rcp_f32 + one Newton step inside 1e-12 <= |a| <= 1e30,
+ * the IEEE division outside) against the IEEE division it stands for (`f = 1.0 / a`, integratorUtilities.cuh:22; 1 / dir, :50-55;
+ * rsqrtf, util.cuh:129). out3[0] = inputs whose results differ (the arithmetic contract needs 0 on the device at hand),
+ * out3[1] = inputs inside the fast range, out3[2] = inputs outside it where the bare fast sequence would be wrong (the reason
+ * for the range guard). first_bad (may be NULL): the lowest differing bit pattern, 0xffffffff if none. ~0.1 s. */
+int pt_probe_rcp_exhaustive(unsigned long long* out3, uint32_t* first_bad);
 int pt_probe_camera_rays(const pt_camera* camera, uint64_t seed, int n, const int32_t* xy, float* out_rays6);
 /* rays: n x 6 floats. out_i: n x 4 (valid, triIDX, materialID, backface);
  * out_f: n x 12 (t,u,v, point xyz, normal xyz, uv xy, 0); counters: summed over the n rays. */

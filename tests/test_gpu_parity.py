@@ -42,6 +42,17 @@ def test_math_contract(api, oracle, gpu_ready):
     assert_bits_equal(g["rsqrt"], oracle.rsqrtf(xp), "rsqrt"); assert_bits_equal(g["pow5"], oracle.pow5(xp), "pow5")
 
 
+def test_rcp_exact_equals_the_ieee_quotient_for_every_binary32_input(api, gpu_ready):
+    """pt_device.h rcp_exact (v_rcp_f32 + one Newton step for 1e-12 <= |a| <= 1e30, IEEE division elsewhere) stands for
+    `f = 1.0 / a` (integratorUtilities.cuh:22), 1 / dir (:50-55) and rsqrtf (util.cuh:129). Its bit-exactness is a property of
+    this device's v_rcp_f32 table, so it is re-proven on every box that runs the suite: all 2^32 inputs, no mismatch."""
+    r = api.probe_rcp_exhaustive()
+    assert r["mismatches"] == 0 and r["first_bad"] == 0xffffffff, r
+    lo, hi = np.float32(1e-12).view(np.uint32), np.float32(1.0e30).view(np.uint32)
+    assert r["in_fast_range"] == 2 * (int(hi) - int(lo) + 1), r          # both signs of [1e-12, 1e30]: the fast arm covers what the kernels feed it
+    assert r["bare_wrong_outside"] > 0, r                                 # ... and the range guard is not decoration
+
+
 def test_camera_rays(api, oracle, gpu_ready):
     for cam in (api.Camera.Pinhole((0, 0, 1), 40, 24), api.Camera.NotPinhole((0.2, -0.1, 1.5), 40, 24, (5, 20, -3), 50.0, 0.05, 2.5),
                 api.Camera.NotPinhole((0, 0, 1), 40, 24, (0, 0, 0), 60.0, 0.0, 1.0)):

@@ -42,6 +42,91 @@ PEAK_HBM_GBS = 8000.0                                         # MI355X_MICROARCH
 PEAK_LDS_GBS = CUS * 128 * CLOCK_HZ / 1e9                     # 128 B/clk/CU
 
 
+# ---- which build were the committed counters measured on? --------------------------------------------------------
+# Every entry of profiles/roofline_inputs.json carries `code_sha256`: the hash of the profiled kernel's machine code
+# (the bytes of its symbol in the gfx950 code object inside libptamd.so). bench.py recomputes it from the library it is
+# about to time; a different hash means the kernel was edited after the PMC pass, and the line then reports
+# `"frac": null, "stale_profile": true` instead of dividing an old instruction count by a new time.
+LIB = os.path.join(ROOT, "cudapathtracer_amd", "csrc", "libptamd.so")
+_BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _elf_symbols(elf):
+    """(name, bytes) of every FUNC symbol of a little-endian ELF64 image (the AMDGPU code object)."""
+    import struct
+    if elf[:4] != b"\x7fELF" or elf[4] != 2:
+        return
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]     # name, type, flags, addr, offset, size, link, info, align, entsize
+    for (_, typ, _, _, off, size, link, _, _, entsize) in secs:
+        if typ != 2 or entsize == 0:                                   # SHT_SYMTAB
+            continue
+        stroff = secs[link][4]
+        for k in range(size // entsize):
+            st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, off + k * entsize)
+            if (st_info & 0xf) != 2 or st_size == 0 or st_shndx == 0 or st_shndx >= shnum:           # STT_FUNC, defined
+                continue
+            end = elf.index(b"\0", stroff + st_name)
+            sec = secs[st_shndx]
+            start = sec[4] + (st_value - sec[3])
+            yield elf[stroff + st_name:end].decode(), elf[start:start + st_size]
+
+
+def kernel_code_hashes(lib_path=LIB):
+    """{demangled kernel name (as rocprofv3 prints it, without `void ` and the parameter list): sha256 of its code} for every
+    megakernel / wavefront kernel in the gfx950 code objects bundled in libptamd.so. {} if the library is missing."""
+    import hashlib
+    import struct
+    import subprocess
+    try:
+        blob = open(lib_path, "rb").read()
+    except OSError:
+        return {}
+    found = {}
+    pos = 0
+    while True:
+        i = blob.find(_BUNDLE_MAGIC, pos)
+        if i < 0:
+            break
+        pos = i + len(_BUNDLE_MAGIC)
+        n, = struct.unpack_from("<Q", blob, i + 24)
+        o = i + 32
+        if n > 16:
+            continue
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, o)
+            triple = blob[o + 24:o + 24 + tlen]
+            o += 24 + tlen
+            if b"gfx950" in triple and size:
+                for name, code in _elf_symbols(blob[i + off:i + off + size]):
+                    if "megakernel" in name or "wf_" in name:
+                        found[name] = hashlib.sha256(code).hexdigest()
+    if not found:
+        return {}
+    names = sorted(found)
+    for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+            break
+        except (OSError, subprocess.CalledProcessError):
+            out = None
+    if not out or len(out) < len(names):
+        return dict(found)                                             # mangled names only: nothing will match, every profile reads as stale
+    pretty = {}
+    for m, d in zip(names, out):
+        d = re.sub(r"^void ", "", d.strip())
+        d = re.sub(r"\(pt::KParams\)$", "", d)
+        d = re.sub(r"\(.*\)$", "", d) if d.endswith(")") else d
+        pretty[d] = found[m]
+    return pretty
+
+
+def profile_is_current(entry, hashes):
+    """True if the committed counters were measured on the very code the loaded library holds for that kernel."""
+    return bool(entry) and bool(entry.get("code_sha256")) and hashes.get(entry.get("kernel")) == entry.get("code_sha256")
+
+
 def alg_bytes(c, n_px):
     """32 B/box test, 16 B/node pop, 52 B/triangle test, 96 B/accepted hit, 16 B/pixel."""
     return 32 * c["box_tests"] + 16 * c["node_pops"] + 52 * c["tri_tests"] + 96 * c["hits"] + 16 * n_px
@@ -125,6 +210,9 @@ def collect(outdir, workload, spp, kernel_ms=None):
         raise SystemExit("expected exactly one timed megakernel instantiation in %s, found %s" % (outdir, sorted(per)))
     name, tot = next(iter(per.items()))
     e = {"workload": workload, "spp": int(spp), "kernel": name.replace("void ", ""), "source": os.path.relpath(outdir, ROOT)}
+    e["code_sha256"] = kernel_code_hashes().get(e["kernel"])       # the library the passes ran on (they run it in-tree)
+    if not e["code_sha256"]:
+        raise SystemExit("no code hash for %s in %s" % (e["kernel"], LIB))
     e.update(tot)
     if kernel_ms:
         e["kernel_ms"] = float(kernel_ms)
@@ -132,6 +220,9 @@ def collect(outdir, workload, spp, kernel_ms=None):
 
 
 def check(bench_line):
+    """Recompute every roofline number of a bench line from profiles/roofline_inputs.json. A row whose `frac` is null
+    (stale profile: the kernel was edited after its PMC pass; or no pass committed) is reported and counts as NOT ok
+    unless it says why (`stale_profile`, a `note`, or no `profile` block at all)."""
     b = json.loads(bench_line) if isinstance(bench_line, str) else bench_line
     inputs = load_inputs()
     rows = [("headline", b)] + [("secondary %d" % i, s) for i, s in enumerate(b.get("secondary", []))]
@@ -139,9 +230,17 @@ def check(bench_line):
     for label, line in rows:
         rf, cfg = line["roofline"], line["config"]
         ms = rf["kernel_ms"]
+        if rf.get("frac") is None:
+            explained = bool(rf.get("stale_profile") or rf.get("note") or "profile" not in rf)
+            ok &= explained
+            print("%-12s %-45s bound %-8s frac null (%s)" % (label, cfg["workload"][:45], rf["bound"],
+                                                             "stale profile" if rf.get("stale_profile") else (rf.get("note") or "no PMC pass committed")[:60]))
+            continue
         if rf["bound"] == "valu":
             e = find_entry(inputs, rf["profile"]["workload"], rf["profile"]["spp"], rf["kernel"])
             want = valu_roofline(e, ms)
+            if e is not None and rf.get("code_sha256") and e.get("code_sha256") and e["code_sha256"] != rf["code_sha256"]:
+                want = None                                            # the line used counters of other code
         else:
             want = l1_roofline(rf["global_node_fetches_per_launch"], rf["global_tri_tests_per_launch"], ms)
         same = want is not None and abs(want["frac"] - rf["frac"]) <= 1e-9 * max(1.0, rf["frac"]) and rf["frac"] <= 1.0
