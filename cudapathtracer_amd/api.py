@@ -114,6 +114,7 @@ def lib():
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
     L.pt_scene_flags.argtypes = [vp]
+    L.pt_last_tile_handovers.argtypes = [vp]
     L.pt_set_culling.argtypes = [vp, i32]
     L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
     L.pt_get_option.argtypes = [vp, C.c_char_p, vp]
@@ -447,6 +448,12 @@ class Scene:
     def flags(self):
         f = lib().pt_scene_flags(self.h)
         return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64), "simple": bool(f & 128), "flat_pair": bool(f & 256), "leaf_table": bool(f & 512)}
+
+    def tile_handovers(self):
+        """pt_last_tile_handovers: tiles that changed hands between waves in the last (completed) megakernel launch."""
+        n = lib().pt_last_tile_handovers(self.h)
+        _check(min(n, 0), "pt_last_tile_handovers")
+        return n
 
     def last_kernel_ms(self):
         """Device time of the last launch; raises if that launch did not finish its frame (tile-queue timeout).

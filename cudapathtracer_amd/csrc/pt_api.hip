@@ -83,6 +83,7 @@ struct pt_scene {
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 (or 2) on: scenes of at most 128 nodes / triangles (64- or 128-bit masks)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0, lastLaunchLeafTable = 0;
     bool lastLaunchQueued = false;        // the last megakernel launch used the tile queue (only then is its error word that launch's)
+    int lastLaunchTiles = 0;              // ... and held this many tiles (pt_last_tile_handovers: pushes beyond them are hand-overs)
     int lastLaunchRefill = 0;             // ... and whether it was a REFILL instantiation
     int lastLaunchHbm = -1;               // which megakernel the last launch used (-1: none yet)
     bool wavesHbmForce = false;           // "waves_hbm" 2: ... and the 6-wave kernel whatever the tile count (tests)
@@ -810,6 +811,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         P.gridBlocks = s->numCU * P.wavesPerSimd * 4 / wgWaves;      // n waves per SIMD = 4n waves per CU, in workgroups of wgWaves
     }
     s->lastLaunchQueued = P.queue != nullptr;
+    s->lastLaunchTiles = t.count;
     P.rng = (uint32_t*)s->rng.p; P.out = (float4*)d_tiles; P.pixCounters = d_pixcnt;
     P.totals = count ? (unsigned long long*)s->totals.p : nullptr;
     P.spill = spillEntries > 0 ? (int32_t*)s->spill.p : nullptr;
@@ -972,6 +974,16 @@ static int queue_error(pt_scene* s) {
     if (hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess) return fail(-2, "tile queue read-back failed");
     if (q[3] != 0) return fail(-4, "megakernel tile queue timed out (code %d, %d tiles finished): the frame is incomplete", q[3], q[2]);
     return 0;
+}
+
+// How often did a tile change hands in the last megakernel launch? The ring starts with every tile pushed once (q[1] = tiles);
+// every further push is a wave yielding its tile at the end of a time slice for another wave to continue.
+int pt_last_tile_handovers(pt_scene* s) {
+    if (!s) return fail(-1, "null scene");
+    if (!s->queue.p || s->variant != 0 || !s->lastLaunchQueued) return 0;
+    int q[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
+    return std::max(0, q[1] - s->lastLaunchTiles);
 }
 
 int pt_set_culling(pt_scene* s, int on) {

@@ -6,8 +6,10 @@
 // (interleaved: per-tile cost varies with geometry and path length) of a replicated scene, and ONE gather brings the
 // tile buffers to device 0, which de-interleaves them into scan-line order. The image is bit-identical for any N.
 //
-// Built on the public C ABI only (pt_scene_create, pt_tile_device, pt_render_tiles_device, pt_untile_device): one host
-// thread per device, as a C++ host of the reference would do it. The gather is RCCL point-to-point (grouped
+// Built on the public C ABI only (pt_scene_create, pt_render_tiles_device, pt_untile_device): one host thread per device,
+// as a C++ host of the reference would do it. The threads share nothing writable: each cuts its own tiles out of the
+// caller's frame into its own pinned staging buffer (the frame crosses PCIe once in total, not once per device), owns its
+// scene replica, stream, events and error string, and only device 0's thread touches the gather buffer and the output. The gather is RCCL point-to-point (grouped
 // ncclSend / ncclRecv = ncclGather; xGMI is point-to-point, 33 MB at 1080p, one hop per peer, no ring) with
 // hipMemcpyPeerAsync as the second transport. RCCL is bound at run time (dlopen of librccl.so.1: inside a PyTorch
 // process that resolves to the copy already loaded, in a plain C++ host to /opt/rocm/lib), so that single-GPU users of
@@ -19,7 +21,6 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
-#include <mutex>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -64,8 +65,9 @@ struct Rank {
     int device = 0;
     pt_scene* scene = nullptr;
     hipStream_t stream = nullptr;
-    void* dColors = nullptr; size_t colorsBytes = 0;    // scan-line frame on this device (initial `out`, its tiles are cut from it)
+    void* dColors = nullptr; size_t colorsBytes = 0;    // rank 0 only: the scan-line frame the gathered tiles are de-interleaved into
     void* dTiles = nullptr; size_t tilesBytes = 0;      // this rank's tile-major buffer, padded to the common count
+    void* hStage = nullptr; size_t stageBytes = 0;      // this rank's OWN pinned staging buffer: its tiles of the caller's frame, cut out on the host
     ncclComm_t comm = nullptr;
     int rc = 0; std::string err;
     float kernelMs = 0.0f;
@@ -74,10 +76,13 @@ struct Rank {
 }  // namespace
 
 struct pt_multi {
-    // Ranks that share a device (rehearsals on a box with fewer GPUs than ranks) render one after another: the megakernel
-    // is persistent — its grid fills the chip and its waves wait on a tile queue — so two of them on one device only
-    // oversubscribe it. Ranks on different devices run concurrently.
-    std::mutex deviceLock[PT_MULTI_MAX_DEVICES];
+    // Ranks that share a device (rehearsals on a box with fewer GPUs than ranks; never the case on a real node). The
+    // megakernel is persistent — its grid fills the chip and its waves wait on a tile queue — so several of them on one
+    // device only oversubscribe it: by default such ranks issue their work to the stream of the FIRST rank on that device
+    // and the kernels run in stream order ("same_device" 1). All host threads still run concurrently — every host-side
+    // object of the library (scenes, events, staging buffers, error strings) is exercised as on a real node — and no
+    // host lock is involved. "same_device" 0 gives every rank its own stream: the kernels then co-reside on the device.
+    int sameDeviceOrdered = 1;
     int n = 0;
     std::vector<Rank> ranks;
     void* dGather = nullptr; size_t gatherBytes = 0;    // on device ranks[0].device: [rank][padded tiles][64] float4
@@ -96,6 +101,36 @@ int ensure(void*& p, size_t& have, size_t need) {
     if (hipMalloc(&p, std::max<size_t>(need, 16)) != hipSuccess) return -2;
     have = need;
     return 0;
+}
+int ensure_pinned(void*& p, size_t& have, size_t need) {
+    if (need <= have) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; have = 0;
+    if (hipHostMalloc(&p, std::max<size_t>(need, 16), hipHostMallocDefault) != hipSuccess) return -2;
+    have = need;
+    return 0;
+}
+
+// The tiles of `tr` cut out of the scan-line frame `colors` into tile-major order [local tile][ly * 8 + lx] (what tile_kernel
+// does on the device): lanes outside the image and the padding tiles up to `pad` are zero. Each rank reads only ITS pixels of
+// the caller's frame — 1 / N of it — and uploads them from its own pinned buffer, so the N host threads share nothing
+// writable and the frame crosses PCIe once in total instead of once per device.
+void tile_host(const float* colors, int w, int h, const pt_tile_range& tr, int pad, float* tiles) {
+    const int tilesX = (w + 7) / 8;
+    memset(tiles, 0, (size_t)pad * 64 * 16);
+    for (int lt = 0; lt < tr.count; lt++) {
+        const int tile = tr.first + lt * tr.stride, x0 = (tile % tilesX) * 8, y0 = (tile / tilesX) * 8;
+        const int xs = std::min(8, w - x0), ys = std::min(8, h - y0);
+        for (int ly = 0; ly < ys; ly++)
+            memcpy(tiles + ((size_t)lt * 64 + (size_t)ly * 8) * 4, colors + ((size_t)(y0 + ly) * w + x0) * 4, (size_t)xs * 16);
+    }
+}
+
+// The stream a rank's device work goes to: its own, or (ranks sharing a device, "same_device" 1) the first such rank's.
+hipStream_t stream_of(const pt_multi* m, int r) {
+    if (m->sameDeviceOrdered)
+        for (int q = 0; q < r; q++) if (m->ranks[q].device == m->ranks[r].device) return m->ranks[q].stream;
+    return m->ranks[r].stream;
 }
 
 template <class F>
@@ -158,6 +193,7 @@ void pt_multi_destroy(pt_multi* m) {
         if (k.scene) pt_scene_destroy(k.scene);
         if (k.dColors) (void)hipFree(k.dColors);
         if (k.dTiles) (void)hipFree(k.dTiles);
+        if (k.hStage) (void)hipHostFree(k.hStage);
         if (k.stream) (void)hipStreamDestroy(k.stream);
     }
     if (m->dGather && !m->ranks.empty() && hipSetDevice(m->ranks[0].device) == hipSuccess) (void)hipFree(m->dGather);
@@ -214,6 +250,11 @@ int pt_multi_set_option(pt_multi* m, const char* name, int value) {
         return 0;
     }
     if (!strcmp(name, "self_gather")) { m->selfGather = value != 0; return 0; }
+    if (!strcmp(name, "same_device")) {
+        if (value < 0 || value > 1) return pt_fail_(-1, "pt_multi_set_option: same_device is 0 (own streams: kernels co-reside) or 1 (one stream per device)");
+        m->sameDeviceOrdered = value;
+        return 0;
+    }
     for (Rank& k : m->ranks)                                                   // everything else: per-scene options of every replica
         if (int rc = pt_set_option(k.scene, name, value)) return rc;
     return 0;
@@ -253,20 +294,17 @@ int pt_multi_render(pt_multi* m, const pt_camera* cam, int w, int h, int spp, in
     (void)hipGetDevice(&prev);
     const double t0 = now_ms();
 
-    // ---- phase 1: every rank cuts its tiles out of the initial frame and renders them ----
+    // ---- phase 1: every rank cuts ITS tiles out of the caller's frame (host, own pinned buffer), uploads and renders them ----
     on_each_rank(m, [&](int r, Rank& k) -> int {
         pt_tile_range tr;
         pt_rank_tiles(w, h, r, N, &tr);
-        if (ensure(k.dColors, k.colorsBytes, frameBytes) || ensure(k.dTiles, k.tilesBytes, slotBytes)) { k.err = "hipMalloc failed"; return -2; }
-        if (r == 0 && ensure(m->dGather, m->gatherBytes, slotBytes * (size_t)N)) { k.err = "hipMalloc failed"; return -2; }
-        int firstOnDevice = r;                                             // the lowest rank on this device names its lock
-        for (int q = 0; q < r; q++) if (m->ranks[q].device == k.device) { firstOnDevice = q; break; }
-        std::lock_guard<std::mutex> oneKernelPerDevice(m->deviceLock[firstOnDevice]);
-        if (hipMemcpyAsync(k.dColors, out_rgba_sum, frameBytes, hipMemcpyHostToDevice, k.stream) != hipSuccess) { k.err = "H2D copy failed"; return -2; }
-        if (hipMemsetAsync(k.dTiles, 0, slotBytes, k.stream) != hipSuccess) { k.err = "memset failed"; return -2; }
-        if (int rc = pt_tile_device(w, h, &tr, k.dColors, k.dTiles, k.stream)) return rc;        // colors[pixelIdx] += Li: the sum starts from `out`
-        if (int rc = pt_render_tiles_device(k.scene, cam, w, h, spp, max_depth, integrator, use_mis, seed, &tr, k.dTiles, 0, k.stream)) return rc;
-        if (hipStreamSynchronize(k.stream) != hipSuccess) { k.err = "stream synchronise failed after the render"; return -2; }
+        if (ensure(k.dTiles, k.tilesBytes, slotBytes) || ensure_pinned(k.hStage, k.stageBytes, slotBytes)) { k.err = "allocation of the tile buffers failed"; return -2; }
+        if (r == 0 && (ensure(k.dColors, k.colorsBytes, frameBytes) || ensure(m->dGather, m->gatherBytes, slotBytes * (size_t)N))) { k.err = "hipMalloc failed"; return -2; }
+        hipStream_t st = stream_of(m, r);
+        tile_host(out_rgba_sum, w, h, tr, pad, (float*)k.hStage);          // colors[pixelIdx] += Li: the sum starts from `out`
+        if (hipMemcpyAsync(k.dTiles, k.hStage, slotBytes, hipMemcpyHostToDevice, st) != hipSuccess) { k.err = "H2D copy failed"; return -2; }
+        if (int rc = pt_render_tiles_device(k.scene, cam, w, h, spp, max_depth, integrator, use_mis, seed, &tr, k.dTiles, 0, st)) return rc;
+        if (hipStreamSynchronize(st) != hipSuccess) { k.err = "stream synchronise failed after the render"; return -2; }
         k.kernelMs = pt_last_kernel_ms(k.scene);                            // also reads the tile queue's error word
         return k.kernelMs < 0.0f ? -4 : 0;
     });
@@ -277,24 +315,25 @@ int pt_multi_render(pt_multi* m, const pt_camera* cam, int w, int h, int spp, in
     on_each_rank(m, [&](int r, Rank& k) -> int {
         char* gather0 = (char*)m->dGather;
         if (!collective) return 0;
+        hipStream_t st = stream_of(m, r);
         if (transport == 1) {
             const size_t count = slotBytes / 4;
             ncclResult_t e = g_rccl.GroupStart();
             if (r == 0) {
-                for (int p = (N > 1 ? 1 : 0); p < N && e == ncclSuccess; p++) e = g_rccl.Recv(gather0 + (size_t)p * slotBytes, count, ncclFloat, p, k.comm, k.stream);
-                if (N == 1 && e == ncclSuccess) e = g_rccl.Send(k.dTiles, count, ncclFloat, 0, k.comm, k.stream);      // self_gather rehearsal
+                for (int p = (N > 1 ? 1 : 0); p < N && e == ncclSuccess; p++) e = g_rccl.Recv(gather0 + (size_t)p * slotBytes, count, ncclFloat, p, k.comm, st);
+                if (N == 1 && e == ncclSuccess) e = g_rccl.Send(k.dTiles, count, ncclFloat, 0, k.comm, st);      // self_gather rehearsal
             } else {
-                e = g_rccl.Send(k.dTiles, count, ncclFloat, 0, k.comm, k.stream);
+                e = g_rccl.Send(k.dTiles, count, ncclFloat, 0, k.comm, st);
             }
             ncclResult_t e2 = g_rccl.GroupEnd();
             if (e == ncclSuccess) e = e2;
             if (e != ncclSuccess) { k.err = std::string("RCCL gather failed: ") + g_rccl.GetErrorString(e); return -5; }
         } else if (r > 0 || N == 1) {
-            if (hipMemcpyPeerAsync(gather0 + (size_t)r * slotBytes, m->ranks[0].device, k.dTiles, k.device, slotBytes, k.stream) != hipSuccess) {
+            if (hipMemcpyPeerAsync(gather0 + (size_t)r * slotBytes, m->ranks[0].device, k.dTiles, k.device, slotBytes, st) != hipSuccess) {
                 k.err = "hipMemcpyPeerAsync failed"; return -2;
             }
         }
-        if (hipStreamSynchronize(k.stream) != hipSuccess) { k.err = "stream synchronise failed after the gather"; return -2; }
+        if (hipStreamSynchronize(st) != hipSuccess) { k.err = "stream synchronise failed after the gather"; return -2; }
         return 0;
     });
     const double t2 = now_ms();

@@ -176,6 +176,9 @@ int pt_reset_counters(pt_scene* scene);
  * pt_render_tiles_device MUST check here (or through any later blocking launcher) before it uses
  * the tile buffer. */
 float pt_last_kernel_ms(pt_scene* scene);
+/* Tile hand-overs of the last megakernel launch (call after it has completed): how many times a wave yielded its tile at
+ * the end of a time slice for another wave to continue (0 without time slices). For tests and scheduling measurements. */
+int pt_last_tile_handovers(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
@@ -252,8 +255,10 @@ void pt_rank_tiles(int w, int h, int rank, int world, pt_tile_range* out);
 pt_multi* pt_multi_create(const pt_scene_desc* desc, int n_devices, const int* device_ids);
 void pt_multi_destroy(pt_multi* m);
 /* "gather": 0 auto (RCCL, else peer copies), 1 RCCL, 2 hipMemcpyPeerAsync; "self_gather" 1: with ONE device, still send
- * the tile buffer through the collective (to itself) — a plumbing check for one-GPU machines; any pt_set_option name:
- * applied to every replica. */
+ * the tile buffer through the collective (to itself) — a plumbing check for one-GPU machines; "same_device" 1 (default):
+ * ranks that share a device (rehearsals only) issue to ONE stream of that device, so their persistent kernels — each
+ * sized to fill the chip — run in stream order, 0: every rank its own stream, the kernels co-reside (both bit-identical;
+ * the host threads run concurrently either way); any pt_set_option name: applied to every replica. */
 int pt_multi_set_option(pt_multi* m, const char* name, int value);
 int pt_multi_set_variant(pt_multi* m, int variant);
 /* pt_render over all devices of `m`: host buffer in / out with `+=` semantics like pt_render. stats may be NULL. */

@@ -693,7 +693,7 @@ def test_options_api(api, gpu_ready):
         sc.set_option(name, defaults[name])
 
 
-def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
+def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False, integrator=0):
     """A 64x64 window = 8 runs of 8 consecutive tiles (pt_tile_range is an arithmetic progression of tile ids)."""
     x0, y0, x1, y1 = (int(v) for v in rect)
     tiles_x = (w + 7) // 8
@@ -702,11 +702,11 @@ def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False):
     for ty in range(y0 // 8, y1 // 8):
         tr = api.TileRange(ty * tiles_x + x0 // 8, 1, (x1 - x0) // 8)
         if counters:
-            rc = api.lib().pt_render_counted(sc.h, ctypes.byref(cam), w, h, spp, md, 0, 1, api.SEED, ctypes.byref(tr), col.ctypes.data_as(ctypes.c_void_p),
+            rc = api.lib().pt_render_counted(sc.h, ctypes.byref(cam), w, h, spp, md, integrator, 1, api.SEED, ctypes.byref(tr), col.ctypes.data_as(ctypes.c_void_p),
                                              cnt.ctypes.data_as(ctypes.c_void_p))
             assert rc == 0, api.lib().pt_last_error()
         else:
-            sc.render(cam, w, h, spp, md, tiles=tr, out=col)
+            sc.render(cam, w, h, spp, md, tiles=tr, out=col, integrator=integrator)
     return col[y0:y1, x0:x1], (cnt[y0:y1, x0:x1] if counters else None)
 
 
@@ -724,7 +724,7 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
     s = window_scene(g, os.path.join(scene_dir, case))
     assert s["sha256"] == str(g["scene_sha256"])
     hs = api.HostScene(s["config"])
-    w, h, spp, md = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"])
+    w, h, spp, md, integ = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]), int(g["integrator"])
     opts = {"production": {"waves_hbm": 2}, "generic_bounce": {"waves_hbm": 2, "simple": 0}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
             "counted": {"waves_hbm": 2}, "wavefront": {"wf_wide_wg": 2}, "compact": {"waves_hbm": 2, "compact": 1}}[mode]
     sc = api.Scene(hs, options=opts)
@@ -732,7 +732,7 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
         sc.set_variant("wavefront")
     cam = hs.camera()
     for k, rect in enumerate(g["rects"]):
-        col, cnt = _render_window(api, sc, cam, w, h, spp, md, rect, counters=(mode == "counted"))
+        col, cnt = _render_window(api, sc, cam, w, h, spp, md, rect, counters=(mode == "counted"), integrator=integ)
         assert_bits_equal(col, g["colors"][k], "%s window %d (%s)" % (case, k, mode))
         if mode == "counted":
             assert np.array_equal(cnt, g["counters"][k]), (case, k)
@@ -741,9 +741,56 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
             assert fl["hbm_kernel"] and fl["refill"] and not fl["onchip"] and not fl["culling"], fl
             assert fl["simple"] == (mode != "generic_bounce"), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
     x0, y0, x1, y1 = (int(v) for v in g["rects"][1])
-    ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8)
+    ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8, integrator=integ)
     assert_bits_equal(ocol[y0:y1, x0:x1], g["colors"][1], "fixture == live oracle")
     assert np.array_equal(ocnt[y0:y1, x0:x1], g["counters"][1])
+
+
+def _oracle_tile(osc, w, h, spp, md, x0, y0, integrator=0):
+    """The oracle on ONE 8x8 tile, its eight rows on eight host threads (a pixel's stream is keyed by its global index, so
+    a row is independent of its neighbours; the oracle's own threading is per 8x8 tile and would leave seven cores idle)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def row(k):
+        col = np.zeros((h, w, 4), np.float32)
+        osc.render(rect=(x0, y0 + k, x0 + 8, y0 + k + 1), spp=spp, max_depth=md, integrator=integrator, threads=1, colors=col)
+        return col[y0 + k, x0:x0 + 8].copy()
+    with ThreadPoolExecutor(8) as ex:
+        return np.stack(list(ex.map(row, range(8))))
+
+
+@pytest.mark.parametrize("config", ["C2_cornell_1024spp_depth8", "C3_blob82k_1024spp_depth8", "C4_atrium263k_4096spp_depth16", "C3_blob82k_naive_1024spp_depth8"])
+def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_ready, scene_dir, config):
+    """The reference carries ONE XORWOW stream per pixel through all samples of a render (state reloaded and stored around every
+    sample, deviceCode.cu:294, 541, 568-573). The window fixtures stop at 4 spp; here ONE 8x8 tile (pt_tile_range of one tile)
+    of each BASELINE config is rendered at the config's OWN sample count and depth through the production kernels and compared
+    bit for bit with a live oracle run of the same 64 pixels: 64 streams of 1024 (4096) samples each, where rare events — the
+    range guard of rcp_exact, stack spills, equal-t ties, NaN paths, roulette at depth 16 — have 256 (1024) times the windows'
+    chances to occur, and where the tile changes hands between waves dozens of times (time slices of 512 iterations)."""
+    from cudapathtracer_amd import scenes
+    gen, kw, tile_xy, opts, integ = {
+        "C2_cornell_1024spp_depth8": ("cornell", dict(spp=1024, max_depth=8), (1112, 624), {}, 0),              # the short box's edge against the floor
+        "C3_blob82k_1024spp_depth8": ("blob_in_box", dict(spp=1024, max_depth=8), (1088, 640), {"waves_hbm": 2}, 0),   # the blob's silhouette
+        "C4_atrium263k_4096spp_depth16": ("atrium", dict(spp=4096, max_depth=16), (960, 536), {"waves_hbm": 2}, 0),
+        "C3_blob82k_naive_1024spp_depth8": ("blob_in_box", dict(spp=1024, max_depth=8), (896, 480), {"waves_hbm": 2}, 2),
+    }[config]
+    w, h = 1920, 1080
+    s = getattr(scenes, gen)(os.path.join(scene_dir, "deep_" + gen), width=w, height=h, name="deep_" + gen, **kw)
+    hs = api.HostScene(s["config"])
+    sc = api.Scene(hs, options=opts)
+    x0, y0 = tile_xy
+    tile = (y0 // 8) * ((w + 7) // 8) + x0 // 8
+    col = np.zeros((h, w, 4), np.float32)
+    sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"], tiles=api.TileRange(tile, 1, 1), out=col, integrator=integ)
+    fl = sc.flags()
+    assert fl["time_slices"] and (fl["flat_pair"] if gen == "cornell" else (fl["hbm_kernel"] and fl["simple"] and fl["refill"])), fl
+    assert sc.tile_handovers() >= 8, sc.tile_handovers()          # the one tile's state really travelled between waves
+    want = _oracle_tile(oracle.OracleScene(s["config"]), w, h, kw["spp"], kw["max_depth"], x0, y0, integ)
+    got = col[y0:y0 + 8, x0:x0 + 8]
+    assert np.isfinite(want[..., :3]).all() and float(want[..., :3].sum()) > 0.0
+    assert_bits_equal(got, want, config)
+    outside = col.copy(); outside[y0:y0 + 8, x0:x0 + 8] = 0
+    assert not outside.any()                                       # nothing outside the tile was touched
 
 
 def test_fuzz_scene_depth16(api, oracle, gpu_ready, scene_dir):

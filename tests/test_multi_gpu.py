@@ -91,21 +91,78 @@ def test_multi_errors(api, gpu_ready):
         ms.set_option("gather", 2).render(hs.camera(), 32, 32, 1, 4, integrator=3)
 
 
-@pytest.mark.gpu
-def test_multi_render_full_frame_on_a_scene_in_hbm(api, gpu_ready, scene_dir):
-    """1080p, 82 k triangles, 8 ranks' worth of tile shares rendered through pt_multi (all on this box's one device):
-    the frame equals the single-launch frame; each share is the 4050-tile launch an 8-GPU run gives every GPU."""
+def _frame_82k(api, scene_dir):
     from cudapathtracer_amd import scenes
     cfg = scenes.blob_in_box(os.path.join(scene_dir, "mb82"), 1920, 1080, 2, 6, name="mb82")["config"]
     hs = api.HostScene(cfg)
     full, _ = api.Scene(hs).render(hs.camera(), 1920, 1080, 2, 6)
-    ms = api.MultiScene(hs, 8, device_ids=[0] * 8)
-    got = ms.render(hs.camera(), 1920, 1080, 2, 6)
-    if not np.array_equal(got.view(np.uint32), full.view(np.uint32)):       # say WHICH ranks' tiles differ before failing
-        bad = np.argwhere((got.view(np.uint32) != full.view(np.uint32)).any(axis=-1))
-        tiles = (bad[:, 0] // 8) * 240 + bad[:, 1] // 8
-        again, _ = api.Scene(hs).render(hs.camera(), 1920, 1080, 2, 6)
-        print("differing pixels %d, tiles %d, ranks %s, single-device frame repeatable %s, stats %s" %
-              (len(bad), len(set(tiles.tolist())), sorted(set((tiles % 8).tolist())), np.array_equal(again.view(np.uint32), full.view(np.uint32)), ms.stats))
-    assert_bits_equal(got, full, "8 ranks, 1080p")
+    return hs, full
+
+
+def _explain(api, hs, got, full, stats):
+    """Say WHICH ranks' tiles differ, and how, before failing."""
+    bad = np.argwhere((got.view(np.uint32) != full.view(np.uint32)).any(axis=-1))
+    tiles = (bad[:, 0] // 8) * 240 + bad[:, 1] // 8
+    again, _ = api.Scene(hs).render(hs.camera(), 1920, 1080, 2, 6)
+    g, f = got[bad[:, 0], bad[:, 1], :3], full[bad[:, 0], bad[:, 1], :3]
+    return ("differing pixels %d in %d tiles of ranks %s; got == 0 in %d, got == 2 x expected in %d, got NaN in %d; first (y, x) %s got %s want %s; "
+            "single-device frame repeatable %s; stats %s" %
+            (len(bad), len(set(tiles.tolist())), sorted(set((tiles % 8).tolist())), int((g == 0).all(axis=1).sum()), int((g == 2 * f).all(axis=1).sum()),
+             int(np.isnan(g).any(axis=1).sum()), bad[0].tolist(), g[0].tolist(), f[0].tolist(), np.array_equal(again.view(np.uint32), full.view(np.uint32)), stats))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("same_device", [1, 0])
+def test_multi_render_full_frame_on_a_scene_in_hbm(api, gpu_ready, scene_dir, same_device):
+    """1080p, 82 k triangles, 8 ranks' worth of tile shares rendered through pt_multi (all on this box's one device): the
+    frame equals the single-launch frame; each share is the 4050-tile launch an 8-GPU run gives every GPU. Eight host
+    threads run the library concurrently in both modes; with same_device = 0 the eight persistent megakernels also
+    co-reside on the device (eight streams), with 1 they run in the order they reach the device's one stream."""
+    hs, full = _frame_82k(api, scene_dir)
+    ms = api.MultiScene(hs, 8, device_ids=[0] * 8, options={"same_device": same_device})
+    for frame in range(2):                                                   # second frame: every buffer, stream and event reused
+        got = ms.render(hs.camera(), 1920, 1080, 2, 6)
+        if not np.array_equal(got.view(np.uint32), full.view(np.uint32)):
+            pytest.fail("frame %d, same_device %d: %s" % (frame, same_device, _explain(api, hs, got, full, ms.stats)))
     assert ms.stats["gather"] == "peer_copy" and len(ms.stats["kernel_ms"]) == 8
+    ms.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bounce", ["simple", "generic"])
+def test_concurrent_megakernels_of_separate_scenes_from_one_host_thread(api, gpu_ready, scene_dir, bounce):
+    """Kernel co-residency WITHOUT host concurrency: one host thread launches the eight 4050-tile shares of the frame on eight
+    replicas of the scene and eight streams back to back (pt_render_tiles_device is asynchronous), so eight persistent
+    megakernels — each with its own tile queue, RNG states, spill area and private segment — are in flight on one device at
+    once; then it waits. Every share must equal the single-launch frame's tiles. `generic` forces the bounce with the
+    material dispatch (216 bytes of private segment per lane instead of 32): the co-resident kernels then also share the
+    device's scratch backing store. No tile changes hands here (2 spp: far below a 512-iteration slice) — asserted."""
+    import torch
+    hs, full = _frame_82k(api, scene_dir)
+    w, h = 1920, 1080
+    cam = hs.camera()
+    opts = {"simple": 0} if bounce == "generic" else {}
+    scenes_ = [api.Scene(hs, options=opts) for _ in range(8)]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    bufs = [torch.zeros(4050, 64, 4, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    for rnd in range(2):                                                     # second round: queues, RNG and spill buffers reused
+        for b in bufs:
+            b.zero_()
+        torch.cuda.synchronize()
+        for r in range(8):
+            scenes_[r].render_tiles_device(cam, w, h, 2, 6, bufs[r].data_ptr(), tiles=api.rank_tiles(w, h, r, 8), stream=streams[r].cuda_stream)
+        torch.cuda.synchronize()
+        frame = torch.zeros(h, w, 4, device="cuda")
+        for r in range(8):
+            assert scenes_[r].last_kernel_ms() > 0.0
+            fl = scenes_[r].flags()
+            assert not fl["hbm_kernel"] and fl["refill"] and fl["simple"] == (bounce == "simple"), fl      # the 4-wave kernels of an 8-GPU share
+            assert scenes_[r].tile_handovers() == 0
+            api.untile_device(w, h, bufs[r].data_ptr(), frame.data_ptr(), api.rank_tiles(w, h, r, 8))
+        torch.cuda.synchronize()
+        got = frame.cpu().numpy()
+        if not np.array_equal(got.view(np.uint32), full.view(np.uint32)):
+            pytest.fail("round %d, %s bounce: %s" % (rnd, bounce, _explain(api, hs, got, full, None)))
+    for s in scenes_:
+        s.close()

@@ -85,8 +85,10 @@ def test_oracle_reproduces_window_fixtures(oracle, scene_dir, case):
     sc = oracle.OracleScene(s["config"])
     assert sc.info["n_tris"] == int(g["n_tris"]) > 80000
     for k, (x0, y0, x1, y1) in enumerate(g["rects"]):
-        col, cnt, _ = sc.render(rect=(int(x0), int(y0), int(x1), int(y1)), counters=True, threads=8)
+        col, cnt, _ = sc.render(rect=(int(x0), int(y0), int(x1), int(y1)), counters=True, threads=8, integrator=int(g["integrator"]))
         assert_bits_equal(col[y0:y1, x0:x1], g["colors"][k], "%s window %d" % (case, k))
         assert np.array_equal(cnt[y0:y1, x0:x1], g["counters"][k])
-    if "atrium" in case:
+    if "atrium" in case and int(g["integrator"]) == 0:
         assert int(g["max_depth"]) == 16 and int(g["counters"][..., 7].max()) > 64      # paths long past the roulette depth
+    if int(g["integrator"]) == 2:                                                       # Li_naive_unidirectional: maxDepth is a hard cap, no shadow rays
+        assert int(g["counters"][..., 7].max()) == int(g["spp"]) * int(g["max_depth"]) and int(g["counters"][..., 1].sum()) == 0
