@@ -60,9 +60,10 @@ PT_DEV SceneCache stage_scene_cache(const DeviceScene& S, int cacheNodes, int ca
 #endif
 
 PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
-    if (defer && (ps.flags & kShadowPending)) { ps.LiFinish = ps.Li; ps.flags |= kFinishPending; }   // last NEE term still in flight
-    else acc = acc + ps.Li;                      // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
-    ps.flags &= ~kInPath;
+    const bool wait = defer && (ps.flags & kShadowPending) != 0;     // last NEE term still in flight: Li keeps the sum until apply_pending closes it (pt_path.h: PathState)
+    const V3 sum = acc + ps.Li;                                        // colors[pixelIdx] += Li, deviceCode.cu:540 / :203
+    acc = v3(wait ? acc.x : sum.x, wait ? acc.y : sum.y, wait ? acc.z : sum.z);
+    ps.flags = (ps.flags & ~kInPath) | (wait ? kFinishPending : 0u);
 }
 
 // ---- tile queue of the persistent megakernel -------------------------------------------------
@@ -195,8 +196,10 @@ PT_DEV void megakernel_body(const KParams& P) {
     }
     if (lt >= P.tileCount) break;
     const int tile = P.tileFirst + lt * P.tileStride;
-    const int x = (tile % P.tilesX) * 8 + (lane & 7), y = (tile / P.tilesX) * 8 + (lane >> 3);
-    const bool inImage = (x < P.w) && (y < P.h);
+    // (the pixel coordinates are re-derived from the wave-uniform tile origin where they are needed — the start of a sample —
+    // instead of living in two VGPRs across every traversal)
+    const int tileX0 = (tile % P.tilesX) * 8, tileY0 = (tile / P.tilesX) * 8;
+    const bool inImage = (tileX0 + (lane & 7) < P.w) && (tileY0 + (lane >> 3) < P.h);
 
     const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
     Stack<STACKN> st;
@@ -217,23 +220,21 @@ PT_DEV void megakernel_body(const KParams& P) {
     }
     ps.o = v3(0.0f); ps.d = v3(0.0f); ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
     ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps; ps.depth = 0; ps.guard = 0; ps.msTop = 1; ps.flags = 0;
-    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; ps.LiFinish = v3(0.0f);
-    float4 acc4;
+    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f;
+    V3 acc;                                                 // colors[pixelIdx].xyz; .w is never touched (`+=` of a Li whose w is 0)
     {
         const uint32_t* o = (const uint32_t*)(P.out + (size_t)lt * 64 + lane);
-        acc4 = make_float4(__uint_as_float(state_load(o, shared)), __uint_as_float(state_load(o + 1, shared)),
-                           __uint_as_float(state_load(o + 2, shared)), __uint_as_float(state_load(o + 3, shared)));
+        acc = v3(__uint_as_float(state_load(o, shared)), __uint_as_float(state_load(o + 1, shared)), __uint_as_float(state_load(o + 2, shared)));
     }
-    V3 acc = v3(acc4.x, acc4.y, acc4.z);
     Ctr c = {};
     c.gnodeFrom = (uint32_t)P.gnodeFrom;
     int samplesLeft = fresh ? (inImage ? P.spp : 0) : (int)state_load((const uint32_t*)P.left + (size_t)lt * 64 + lane, true);
     Hit h; h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
     V3 thr = v3(1.0f);
     RayState rs;                                          // REFILL: a lane's traversal state between two visits of the loops
-    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.inv = v3(0.0f); rs.max_t = 0.0f; rs.min_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
+    rs.o = v3(0.0f); rs.d = v3(0.0f); rs.max_t = 0.0f; rs.cur = kRefNone; rs.flags = 0u;
 #ifdef PT_EXPERIMENTAL
-    rs.pend = kRefNone;
+    rs.inv = v3(0.0f); rs.min_t = 0.0f; rs.pend = kRefNone;
 #endif
 #ifdef PT_STAMPS
     unsigned long long stamp[4] = {0, 0, 0, 0};
@@ -305,7 +306,8 @@ PT_DEV void megakernel_body(const KParams& P) {
             // Lanes whose rays are done take their logic step (DEFER form: the shadow ray is recorded, not traced
             // inside the bounce) and start their next pair of rays; lanes still tracing skip it and resume below.
             if (!(rs.flags & kRayBusy)) {
-                apply_pending(ps, thr, acc);
+                if constexpr (SIMPLE) thr = (rs.flags & kRayOccluded) ? v3(0.0f) : v3(1.0f);      // NOLEAF: the shadow ray's result is one flag bit (pt_trace.h: RayState)
+                apply_pending<SIMPLE>(ps, thr, acc);
                 if (ps.flags & kInPath) {
                     bool done = path_bounce<INTEG, COUNT, true, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
                     if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
@@ -313,7 +315,7 @@ PT_DEV void megakernel_body(const KParams& P) {
                 }
                 while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
                     samplesLeft--;
-                    path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+                    path_begin<COUNT>(P.cam, ps, ms, tileX0 + (lane & 7), tileY0 + (lane >> 3), c);
                     if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, true);
                 }
                 const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
@@ -370,7 +372,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             PT_STAMP(1);
             continue;
         }
-        if (DEFER) apply_pending(ps, thr, acc);
+        if (DEFER) apply_pending<SIMPLE>(ps, thr, acc);
         if (ps.flags & kInPath) {
             bool done = path_bounce<INTEG, COUNT, DEFER, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
             if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
@@ -379,7 +381,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(2);                                   // slot 2: scheduling check + bounce logic (shading, NEE shadow ray)
         while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
             samplesLeft--;
-            path_begin<COUNT>(P.cam, ps, ms, x, y, c);
+            path_begin<COUNT>(P.cam, ps, ms, tileX0 + (lane & 7), tileY0 + (lane >> 3), c);
             if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, DEFER);
         }
         const bool hasExt = (ps.flags & kInPath) != 0;
@@ -423,7 +425,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     if (inImage) {
         uint32_t* o = (uint32_t*)(P.out + (size_t)lt * 64 + lane);
         state_store(o, __float_as_uint(acc.x), shared); state_store(o + 1, __float_as_uint(acc.y), shared);
-        state_store(o + 2, __float_as_uint(acc.z), shared); state_store(o + 3, __float_as_uint(acc4.w), shared);
+        state_store(o + 2, __float_as_uint(acc.z), shared);
     }
     {
         uint32_t* r = P.rng + (size_t)lt * 384 + lane;

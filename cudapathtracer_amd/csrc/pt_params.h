@@ -51,8 +51,16 @@ constexpr int kCacheBytesHbm = kWgWavesHbm == 4 ? kCacheBytes
 // kernel's code and holds less state: it runs best at 8 waves per SIMD (64 VGPRs) in workgroups of 16 waves — one LDS copy
 // of the top of the tree per 16 waves, and no medium stacks, so the copy is 48 KB (768 PNodes). The generic kernel is 13 %
 // SLOWER at 8 (spills) and stays at PT_WAVES_HBM (profiles/r02_ab_waves_simple.log).
-constexpr int kWavesHbmSimple = 8, kWgWavesHbmSimple = 16;
-constexpr int kCacheBytesHbmSimple = ((160 * 1024) / 2 - kWgWavesHbmSimple * (kStackLdsHbm * 256)) / 64 * 64;
+#ifndef PT_WAVES_HBM_SIMPLE
+#define PT_WAVES_HBM_SIMPLE 8
+#endif
+#ifndef PT_WG_WAVES_HBM_SIMPLE
+#define PT_WG_WAVES_HBM_SIMPLE 16
+#endif
+constexpr int kWavesHbmSimple = PT_WAVES_HBM_SIMPLE, kWgWavesHbmSimple = PT_WG_WAVES_HBM_SIMPLE;
+static_assert((kWavesHbmSimple * 4) % kWgWavesHbmSimple == 0 && kWgWavesHbmSimple <= 16, "the workgroups of the SIMPLE kernel must tile a CU's wave slots");
+constexpr int kWgPerCuHbmSimple = (kWavesHbmSimple * 4) / kWgWavesHbmSimple;        // a CU's 160 KB of LDS divided among them
+constexpr int kCacheBytesHbmSimple = ((160 * 1024) / kWgPerCuHbmSimple - kWgWavesHbmSimple * (kStackLdsHbm * 256)) / 64 * 64;
 
 struct KParams {
     DeviceScene S;

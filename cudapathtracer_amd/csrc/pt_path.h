@@ -48,7 +48,7 @@ enum : uint32_t {
     kHitFirstNonSpec = 2u,   // hitFirstnonSpecular, deviceCode.cu:316
     kShadowPending = 4u,     // DEFER: (so, sd, smaxt) must be traced and applied
     kNeeValid = 8u,          // DEFER: the recorded NEE sample had light_pdf > EPSILON
-    kFinishPending = 16u,    // DEFER: the previous path ended with its last NEE term still pending
+    kFinishPending = 16u,    // DEFER: the previous path ended with its last NEE term still pending: `Li` still holds ITS sum
 };
 
 struct PathState {
@@ -58,10 +58,12 @@ struct PathState {
     float pdf, etaI, etaT;
     int depth, guard, msTop;
     uint32_t flags;
-    // DEFER only
+    // DEFER only. (so, sd, smaxt) are read once, right after the bounce that wrote them, to start the shadow ray: they are not
+    // live across a traversal. kFinishPending: the finished path's sum stays in `Li` until apply_pending has added its last NEE
+    // term — the path that follows starts at Li = 0 and receives nothing before that apply_pending, so one register triple
+    // serves both (three VGPRs less across every traversal; the kernel for scenes in HBM lives at 64).
     V3 so, sd; float smaxt;  // pending shadow ray
-    V3 neeRaw, neeBeta; float neeW;
-    V3 LiFinish;
+    V3 neeRaw, neeBeta; float neeW;      // PRE (scenes without MAT_LEAF triangles): neeRaw holds the finished term (beta * nee) * w, the other two are unused
 };
 
 // mediumStack[16] (deviceCode.cu:306) — in LDS for the megakernel, packed in 4 registers for the
@@ -103,26 +105,30 @@ PT_DEV void medium_remove(MS& ms, int& top, int materialID) {
 template <bool COUNT, class MS>
 PT_DEV void path_begin(const CamK& cam, PathState& ps, MS& ms, int x, int y, Ctr& c) {
     camera_ray<COUNT>(cam, ps.rng, x, y, ps.o, ps.d, c);
-    ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
+    const bool fin = (ps.flags & kFinishPending) != 0;       // Li still holds the finished path's sum (see PathState); this path's own Li is 0 until then
+    ps.beta = v3(1.0f); ps.Li = v3(fin ? ps.Li.x : 0.0f, fin ? ps.Li.y : 0.0f, fin ? ps.Li.z : 0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
     ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps;
     ps.depth = 0; ps.guard = 0; ps.msTop = 1; ms.set(0, 0);
     ps.flags = (ps.flags & ~kHitFirstNonSpec) | kInPath;
 }
 
-// DEFER: add the NEE term recorded by the previous bounce (and close a path that ended on it).
+// DEFER: add the NEE term recorded by the previous bounce (and close a path that ended on it): `Li += (beta * (nee * thr)) * w`
+// exactly as deviceCode.cu:153 groups it, then — if that path had ended — `colors[pixelIdx] += Li` (:540).
+// PRE: no triangle of the scene is a MAT_LEAF, so a shadow ray's throughput is exactly 0 or exactly 1 (BVHShadowRay,
+// integratorUtilities.cuh:188-288); nee * 1.0f == nee bit for bit, and the bounce has recorded the finished term.
+template <bool PRE = false>
 PT_DEV void apply_pending(PathState& ps, V3 thr, V3& acc) {
     // (value selects only: a branch that picks WHICH field to update becomes a pointer select and
     // forces the whole PathState into scratch memory)
     const bool fin = (ps.flags & kFinishPending) != 0;
-    if ((ps.flags & kShadowPending) && (ps.flags & kNeeValid) && dot(thr, thr) > 0.0f) {
-        V3 nee = ps.neeRaw * thr;
-        V3 term = (ps.neeBeta * nee) * ps.neeW;
-        V3 base = v3(fin ? ps.LiFinish.x : ps.Li.x, fin ? ps.LiFinish.y : ps.Li.y, fin ? ps.LiFinish.z : ps.Li.z);
-        V3 sum = base + term;
-        ps.Li = v3(fin ? ps.Li.x : sum.x, fin ? ps.Li.y : sum.y, fin ? ps.Li.z : sum.z);
-        ps.LiFinish = v3(fin ? sum.x : ps.LiFinish.x, fin ? sum.y : ps.LiFinish.y, fin ? sum.z : ps.LiFinish.z);
-    }
-    if (fin) acc = acc + ps.LiFinish;
+    const bool add = (ps.flags & kShadowPending) && (ps.flags & kNeeValid) && dot(thr, thr) > 0.0f;
+    V3 term = ps.neeRaw;
+    if (!PRE) term = (ps.neeBeta * (ps.neeRaw * thr)) * ps.neeW;
+    const V3 sum = ps.Li + term;
+    const V3 li = v3(add ? sum.x : ps.Li.x, add ? sum.y : ps.Li.y, add ? sum.z : ps.Li.z);
+    const V3 done = acc + li;
+    acc = v3(fin ? done.x : acc.x, fin ? done.y : acc.y, fin ? done.z : acc.z);
+    ps.Li = v3(fin ? 0.0f : li.x, fin ? 0.0f : li.y, fin ? 0.0f : li.z);
     ps.flags &= ~(kShadowPending | kNeeValid | kFinishPending);
 }
 
@@ -278,7 +284,8 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
                     else pdf_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy, pdfB);
                     float wN = lightPdf * lightPdf / (pdfB * pdfB + lightPdf * lightPdf);
                     if (DEFER) {
-                        nr.neeRaw = nee; nr.neeBeta = beta; nr.neeW = wN;
+                        if (SIMPLE) nr.neeRaw = (beta * nee) * wN;            // apply_pending<PRE>: the finished term (thr is exactly 1 when it is added)
+                        else { nr.neeRaw = nee; nr.neeBeta = beta; nr.neeW = wN; }
                         flags |= kNeeValid;
                     } else {
                         pdf = pdfB;
@@ -329,8 +336,10 @@ PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& 
     float pdf = ps.pdf, etaI = ps.etaI, etaT = ps.etaT;
     int depth = ps.depth, msTop = ps.msTop;
     uint32_t flags = ps.flags;
+    // (a fresh record, not a copy of the previous bounce's: whatever the last bounce recorded was consumed — the shadow ray
+    // started, the term applied — before this bounce runs, so the old values are dead here and not live across the traversal)
     NeeRecord nr;
-    nr.so = ps.so; nr.sd = ps.sd; nr.smaxt = ps.smaxt; nr.neeRaw = ps.neeRaw; nr.neeBeta = ps.neeBeta; nr.neeW = ps.neeW;
+    nr.so = v3(0.0f); nr.sd = v3(0.0f); nr.smaxt = 0.0f; nr.neeRaw = v3(0.0f); nr.neeBeta = v3(0.0f); nr.neeW = 0.0f;
     bool done = bounce_core<INTEG, COUNT, DEFER, SIMPLE>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
                                                  ms, h, maxDepth, useMIS, shadow, c);
     ps.rng = rng;

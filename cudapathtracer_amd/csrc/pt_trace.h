@@ -918,29 +918,35 @@ struct Trav {
 // the lanes that finished run their logic step (shade, next-event record, regenerate) and come back with new
 // rays while the others simply continue where they stopped. Per ray the visiting order, the tests and the
 // counters are those of trace_closest / trace_shadow.
+// What a lane keeps between two calls is kept small on purpose — the kernel for scenes in HBM runs at 64 VGPRs and every
+// register that lives across the loops below is one it spills around the logic step: the reciprocal direction is recomputed
+// on entry (a dozen instructions per call against hundreds of node steps), the best t so far lives in the caller's Hit (h.t,
+// FLT_MAX until something is hit), and the shadow ray of a scene without MAT_LEAF triangles reports "occluded" in a flag bit
+// instead of a three-register throughput.
 struct RayState {
-    V3 o, d, inv;
-    float max_t, min_t;
+    V3 o, d;
+    float max_t;
     int32_t cur;
 #ifdef PT_EXPERIMENTAL
+    V3 inv; float min_t;
     int32_t pend;                      // trace_resume_spec / trace_resume_q: the one postponed leaf (kRefNone = none)
 #endif
-    uint32_t flags;                    // kRayBusy | kRayShadow | kRayExtFollows
+    uint32_t flags;                    // kRayBusy | kRayShadow | kRayExtFollows | kRayOccluded
 };
-constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u, kRayInLeaf = 32u;     // (8u, 16u and kRayInLeaf: pt_trace_experimental.h)
+constexpr uint32_t kRayBusy = 1u, kRayShadow = 2u, kRayExtFollows = 4u, kRayInLeaf = 32u, kRayOccluded = 64u;     // (8u, 16u and kRayInLeaf: pt_trace_experimental.h)
 
 template <bool COUNT, int N>
 PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasShadow, V3 so, V3 sd, float smaxt,
                       bool hasExt, V3 eo, V3 ed, V3& thr, Hit& h, Ctr& c) {
-    h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
+    h.tri = -1; h.t = 3.402823466e+38f; h.u = 0.0f; h.v = 0.0f; h.material = 0;      // h.t: the running minimum (BVHSceneIntersect's min_t) until a triangle sets it
     thr = v3(1.0f);
     if (COUNT) { if (hasShadow) c.raysShadow++; if (hasExt) c.raysClosest++; }
     r.o = hasShadow ? so : eo; r.d = hasShadow ? sd : ed;
-    r.inv = inv3(r.d);
     r.max_t = hasShadow ? smaxt : 999999.0f;
-    r.min_t = 3.402823466e+38f;
     r.cur = S.rootRef;
 #ifdef PT_EXPERIMENTAL
+    r.inv = inv3(r.d);
+    r.min_t = 3.402823466e+38f;
     r.pend = kRefNone;
 #endif
     r.flags = kRayBusy | (hasShadow ? kRayShadow : 0u) | ((hasShadow && hasExt) ? kRayExtFollows : 0u);
@@ -953,10 +959,10 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
                          V3& thr, Hit& h, Ctr& c, Keep k = Keep{0, 0}) {
     typedef LoopExit<ONCHIP> X;
     if (!(r.flags & kRayBusy)) return;
-    V3 o = r.o, d = r.d, inv = r.inv;
-    float max_t = r.max_t, min_t = r.min_t;
+    V3 o = r.o, d = r.d, inv = inv3(r.d);
+    float max_t = r.max_t;
     int32_t cur = r.cur;
-    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true, occl = (r.flags & kRayOccluded) != 0;
     while (true) {
         // wave-level early exit: the lanes still here keep their state for the next call
         const int active = lanes_here();
@@ -996,7 +1002,8 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
             if (isShadow) {
                 if (ok && (t < max_t)) {
                     uint32_t flags = f2u(q.e.w);
-                    if (NOLEAF || !(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                    if (NOLEAF) { occl = true; occluded = true; break; }             // the caller reads kRayOccluded; thr is not touched
+                    if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
                     // MAT_LEAF (integratorUtilities.cuh:218-239)
                     const PMat& m = S.mats[f2i(q.e.z)];
                     const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -1008,8 +1015,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
                     thr = thr * sc;
                     if (fmaxf_(thr.x, fmaxf_(thr.y, thr.z)) < 0.01f) { thr = v3(0.0f); occluded = true; break; }
                 }
-            } else if (ok && (t < min_t) && (t < max_t)) {
-                min_t = t;
+            } else if (ok && (t < h.t) && (t < max_t)) {                              // h.t is min_t (ray_start)
                 h.t = t; h.u = u; h.v = v;
                 h.tri = (int32_t)(idx & 0x7fffffffu);
                 h.material = f2i(q.e.z);
@@ -1022,8 +1028,8 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
         if (COUNT) c.pops++;
         cur = (!occluded && st.sp > 0) ? st.template pop<ONCHIP>() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
     }
-    r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur;
-    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
+    r.o = o; r.d = d; r.max_t = max_t; r.cur = cur;
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | (occl ? kRayOccluded : 0u);
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }
 

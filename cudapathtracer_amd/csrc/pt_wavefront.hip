@@ -25,7 +25,7 @@ enum WfF : int {   // float fields
     F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_BX, F_BY, F_BZ, F_LIX, F_LIY, F_LIZ, F_PPX, F_PPY, F_PPZ, F_WOX, F_WOY, F_WOZ,
     F_PDF, F_ETAI, F_ETAT,
     F_SOX, F_SOY, F_SOZ, F_SDX, F_SDY, F_SDZ, F_SMAXT,
-    F_NRX, F_NRY, F_NRZ, F_NBX, F_NBY, F_NBZ, F_NW, F_LFX, F_LFY, F_LFZ, F_ACX, F_ACY, F_ACZ,
+    F_NRX, F_NRY, F_NRZ, F_NBX, F_NBY, F_NBZ, F_NW, F_ACX, F_ACY, F_ACZ,
     F_COUNT
 };
 enum WfU : int {   // uint32 fields
@@ -35,18 +35,20 @@ enum WfU : int {   // uint32 fields
 // results per RAY slot (extension ray of path p: slot p; shadow ray of path p: slot n + p)
 enum WfR : int { R_T, R_U, R_V, R_TRI, R_MAT, R_THRX, R_THRY, R_THRZ, R_POPS, R_BOXES, R_TRIS, R_COUNT };
 
-// SIMPLE (diffuse-only scenes, pt_path.h): the medium stack words, its top and the two indices of refraction are never read.
+// SIMPLE (diffuse-only scenes, pt_path.h): the medium stack words, its top, the two indices of refraction, the sampled local
+// direction and — the bounce records the finished NEE term (apply_pending<PRE>) — the term's beta and weight are never read.
 template <bool SIMPLE = false>
 PT_DEV void wf_load(const WfParams& W, int p, PathState& ps, RegMedium& ms, V3& acc, int& samplesLeft) {
     const float* F = W.F + p; const uint32_t* U = W.U + p; const size_t n = W.n;
     ps.o = v3(F[F_OX * n], F[F_OY * n], F[F_OZ * n]); ps.d = v3(F[F_DX * n], F[F_DY * n], F[F_DZ * n]);
     ps.beta = v3(F[F_BX * n], F[F_BY * n], F[F_BZ * n]); ps.Li = v3(F[F_LIX * n], F[F_LIY * n], F[F_LIZ * n]);
-    ps.prevPoint = v3(F[F_PPX * n], F[F_PPY * n], F[F_PPZ * n]); ps.woLocal = v3(F[F_WOX * n], F[F_WOY * n], F[F_WOZ * n]);
+    ps.prevPoint = v3(F[F_PPX * n], F[F_PPY * n], F[F_PPZ * n]);
+    ps.woLocal = SIMPLE ? v3(0.0f) : v3(F[F_WOX * n], F[F_WOY * n], F[F_WOZ * n]);
     ps.pdf = F[F_PDF * n];
     if (SIMPLE) { ps.etaI = kEps; ps.etaT = kEps; } else { ps.etaI = F[F_ETAI * n]; ps.etaT = F[F_ETAT * n]; }
     ps.so = v3(F[F_SOX * n], F[F_SOY * n], F[F_SOZ * n]); ps.sd = v3(F[F_SDX * n], F[F_SDY * n], F[F_SDZ * n]); ps.smaxt = F[F_SMAXT * n];
-    ps.neeRaw = v3(F[F_NRX * n], F[F_NRY * n], F[F_NRZ * n]); ps.neeBeta = v3(F[F_NBX * n], F[F_NBY * n], F[F_NBZ * n]); ps.neeW = F[F_NW * n];
-    ps.LiFinish = v3(F[F_LFX * n], F[F_LFY * n], F[F_LFZ * n]);
+    ps.neeRaw = v3(F[F_NRX * n], F[F_NRY * n], F[F_NRZ * n]);
+    if (SIMPLE) { ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; } else { ps.neeBeta = v3(F[F_NBX * n], F[F_NBY * n], F[F_NBZ * n]); ps.neeW = F[F_NW * n]; }
     acc = v3(F[F_ACX * n], F[F_ACY * n], F[F_ACZ * n]);
     ps.rng.v0 = U[U_R0 * n]; ps.rng.v1 = U[U_R1 * n]; ps.rng.v2 = U[U_R2 * n]; ps.rng.v3 = U[U_R3 * n]; ps.rng.v4 = U[U_R4 * n]; ps.rng.d = U[U_RD * n];
     ps.depth = (int)U[U_DEPTH * n]; ps.guard = (int)U[U_GUARD * n]; ps.flags = U[U_FLAGS * n];
@@ -61,13 +63,12 @@ PT_DEV void wf_store(const WfParams& W, int p, const PathState& ps, const RegMed
     F[F_OX * n] = ps.o.x; F[F_OY * n] = ps.o.y; F[F_OZ * n] = ps.o.z; F[F_DX * n] = ps.d.x; F[F_DY * n] = ps.d.y; F[F_DZ * n] = ps.d.z;
     F[F_BX * n] = ps.beta.x; F[F_BY * n] = ps.beta.y; F[F_BZ * n] = ps.beta.z; F[F_LIX * n] = ps.Li.x; F[F_LIY * n] = ps.Li.y; F[F_LIZ * n] = ps.Li.z;
     F[F_PPX * n] = ps.prevPoint.x; F[F_PPY * n] = ps.prevPoint.y; F[F_PPZ * n] = ps.prevPoint.z;
-    F[F_WOX * n] = ps.woLocal.x; F[F_WOY * n] = ps.woLocal.y; F[F_WOZ * n] = ps.woLocal.z;
+    if (!SIMPLE) { F[F_WOX * n] = ps.woLocal.x; F[F_WOY * n] = ps.woLocal.y; F[F_WOZ * n] = ps.woLocal.z; }
     F[F_PDF * n] = ps.pdf;
     if (!SIMPLE) { F[F_ETAI * n] = ps.etaI; F[F_ETAT * n] = ps.etaT; }
     F[F_SOX * n] = ps.so.x; F[F_SOY * n] = ps.so.y; F[F_SOZ * n] = ps.so.z; F[F_SDX * n] = ps.sd.x; F[F_SDY * n] = ps.sd.y; F[F_SDZ * n] = ps.sd.z; F[F_SMAXT * n] = ps.smaxt;
     F[F_NRX * n] = ps.neeRaw.x; F[F_NRY * n] = ps.neeRaw.y; F[F_NRZ * n] = ps.neeRaw.z;
-    F[F_NBX * n] = ps.neeBeta.x; F[F_NBY * n] = ps.neeBeta.y; F[F_NBZ * n] = ps.neeBeta.z; F[F_NW * n] = ps.neeW;
-    F[F_LFX * n] = ps.LiFinish.x; F[F_LFY * n] = ps.LiFinish.y; F[F_LFZ * n] = ps.LiFinish.z;
+    if (!SIMPLE) { F[F_NBX * n] = ps.neeBeta.x; F[F_NBY * n] = ps.neeBeta.y; F[F_NBZ * n] = ps.neeBeta.z; F[F_NW * n] = ps.neeW; }
     F[F_ACX * n] = acc.x; F[F_ACY * n] = acc.y; F[F_ACZ * n] = acc.z;
     U[U_R0 * n] = ps.rng.v0; U[U_R1 * n] = ps.rng.v1; U[U_R2 * n] = ps.rng.v2; U[U_R3 * n] = ps.rng.v3; U[U_R4 * n] = ps.rng.v4; U[U_RD * n] = ps.rng.d;
     U[U_DEPTH * n] = (uint32_t)ps.depth; U[U_GUARD * n] = (uint32_t)ps.guard; U[U_FLAGS * n] = ps.flags;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) wf_init_kernel(WfParams W, int spp) {
     PathState ps;
     ps.o = v3(0.0f); ps.d = v3(0.0f); ps.beta = v3(1.0f); ps.Li = v3(0.0f); ps.prevPoint = v3(0.0f); ps.woLocal = v3(0.0f);
     ps.pdf = kEps; ps.etaI = kEps; ps.etaT = kEps; ps.depth = 0; ps.guard = 0; ps.msTop = 1; ps.flags = 0;
-    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f; ps.LiFinish = v3(0.0f);
+    ps.so = v3(0.0f); ps.sd = v3(0.0f); ps.smaxt = 0.0f; ps.neeRaw = v3(0.0f); ps.neeBeta = v3(0.0f); ps.neeW = 0.0f;
     const uint32_t* r = W.rng + (size_t)lt * 384 + lane;
     ps.rng.v0 = r[0]; ps.rng.v1 = r[64]; ps.rng.v2 = r[128]; ps.rng.v3 = r[192]; ps.rng.v4 = r[256]; ps.rng.d = r[320];
     float4 a = W.out[p];
@@ -136,12 +137,13 @@ __global__ void __launch_bounds__(256) wf_logic_kernel(WfParams W, DeviceScene S
                 if (COUNT) { c.raysShadow++; c.pops += __builtin_bit_cast(uint32_t, R[R_POPS * 2 * n]); c.boxes += __builtin_bit_cast(uint32_t, R[R_BOXES * 2 * n]); c.tris += __builtin_bit_cast(uint32_t, R[R_TRIS * 2 * n]); }
             }
             auto noShadow = [](V3, V3, float) { return v3(1.0f); };
-            apply_pending(ps, thr, acc);
+            apply_pending<SIMPLE>(ps, thr, acc);
             if (ps.flags & kInPath) {
                 bool done = path_bounce<INTEG, COUNT, true, SIMPLE>(S, ps, ms, h, maxDepth, useMIS, noShadow, c);
                 if (!done) done = path_exhausted<INTEG>(ps, maxDepth);
                 if (done) {
-                    if (ps.flags & kShadowPending) { ps.LiFinish = ps.Li; ps.flags |= kFinishPending; } else acc = acc + ps.Li;
+                    if (ps.flags & kShadowPending) ps.flags |= kFinishPending;      // Li keeps the sum until the last NEE term is in (pt_path.h: PathState)
+                    else acc = acc + ps.Li;
                     ps.flags &= ~kInPath;
                 }
             }

@@ -784,7 +784,7 @@ def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_r
     sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"], tiles=api.TileRange(tile, 1, 1), out=col, integrator=integ)
     fl = sc.flags()
     assert fl["time_slices"] and (fl["flat_pair"] if gen == "cornell" else (fl["hbm_kernel"] and fl["simple"] and fl["refill"])), fl
-    assert sc.tile_handovers() >= 8, sc.tile_handovers()          # the one tile's state really travelled between waves
+    assert sc.tile_handovers() >= 4, sc.tile_handovers()          # the one tile's state really travelled between waves
     want = _oracle_tile(oracle.OracleScene(s["config"]), w, h, kw["spp"], kw["max_depth"], x0, y0, integ)
     got = col[y0:y0 + 8, x0:x0 + 8]
     assert np.isfinite(want[..., :3]).all() and float(want[..., :3].sum()) > 0.0

@@ -83,3 +83,40 @@ def test_no_agent_scope_fences_in_the_megakernels(isa):
     measured 3x slower on the 263 k-triangle scene. The tile queue must not need one."""
     for name, body in _functions(isa).items():
         assert "buffer_wbl2" not in body and not re.search(r"buffer_inv\s+sc1", body), name
+
+
+def _metadata(text):
+    """{mangled kernel name: {vgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size}} from the code-object notes."""
+    out = {}
+    cur = None
+    for ln in text.split("\n"):
+        s = ln.strip()
+        m = re.match(r"\.name:\s+(_ZN2pt\d+megakernel\w+)$", s)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)$", s)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return {k: v for k, v in out.items() if len(v) == 4}
+
+
+def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
+    """What the timed instantiations cost in registers and scratch, pinned so that a change that pushes state back across
+    the traversal loops shows up here and not as a slower frame (the DEFER path state was cut to what a
+    path needs ACROSS a traversal — no pending-shadow ray, one NEE term instead of three factors, one Li for both the
+    finished and the new path, no reciprocal direction, no min_t, no pixel coordinates):
+      * the headline kernels (LDS-resident, 4 waves per SIMD, 128 VGPRs) and the 4-wave SIMPLE kernel an 8-GPU share runs:
+        no private segment at all;
+      * the production kernel for scenes in HBM (8 waves per SIMD): 64 VGPRs, and a private segment that may not grow — its
+        logic step peaks at ~125 live registers (no spill at a cap of 128, 31 spill sites at 96, 86 at 80, 159 at 64), the
+        price of eight waves per SIMD that measures 2 % FASTER than six with 86 (profiles/r03_ab_hbm_simple_shapes_*.log)."""
+    md = _metadata(isa)
+    flat2 = md["_ZN2pt16megakernel_flat2ILi0ELb1EEEvNS_7KParamsE"]
+    assert flat2["vgpr_count"] <= 128 and flat2["private_segment_fixed_size"] == 0 and flat2["vgpr_spill_count"] == 0, flat2
+    share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1EEEvNS_7KParamsE"]        # megakernel<0, false, false, false, true, false, true>: 4-wave REFILL SIMPLE
+    assert share["vgpr_count"] <= 128 and share["private_segment_fixed_size"] == 0 and share["vgpr_spill_count"] == 0, share
+    hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
+    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 264, hbm
+    gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0EEEvNS_7KParamsE"]                    # generic bounce, REFILL, 6 waves per SIMD
+    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 380, gen
