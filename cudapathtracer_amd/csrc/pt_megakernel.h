@@ -198,8 +198,20 @@ PT_DEV void megakernel_body(const KParams& P) {
     const int tile = P.tileFirst + lt * P.tileStride;
     // (the pixel coordinates are re-derived from the wave-uniform tile origin where they are needed — the start of a sample —
     // instead of living in two VGPRs across every traversal)
+#ifndef PT_XY_VGPR
+#define PT_XY_VGPR 0
+#endif
+#if PT_XY_VGPR
+    const int tileX0 = (tile % P.tilesX) * 8 + (lane & 7), tileY0 = (tile / P.tilesX) * 8 + (lane >> 3);      // (per-lane x, y)
+    const bool inImage = (tileX0 < P.w) && (tileY0 < P.h);
+#define PT_PX (tileX0)
+#define PT_PY (tileY0)
+#else
     const int tileX0 = (tile % P.tilesX) * 8, tileY0 = (tile / P.tilesX) * 8;
     const bool inImage = (tileX0 + (lane & 7) < P.w) && (tileY0 + (lane >> 3) < P.h);
+#define PT_PX (tileX0 + (lane & 7))
+#define PT_PY (tileY0 + (lane >> 3))
+#endif
 
     const int cacheBytes = P.cacheNodes * 64 + P.cacheTris * 48;
     Stack<STACKN> st;
@@ -315,7 +327,7 @@ PT_DEV void megakernel_body(const KParams& P) {
                 }
                 while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
                     samplesLeft--;
-                    path_begin<COUNT>(P.cam, ps, ms, tileX0 + (lane & 7), tileY0 + (lane >> 3), c);
+                    path_begin<COUNT>(P.cam, ps, ms, PT_PX, PT_PY, c);
                     if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, true);
                 }
                 const bool hasExt = (ps.flags & kInPath) != 0, hasShadow = (ps.flags & kShadowPending) != 0;
@@ -381,7 +393,7 @@ PT_DEV void megakernel_body(const KParams& P) {
         PT_STAMP(2);                                   // slot 2: scheduling check + bounce logic (shading, NEE shadow ray)
         while (!(ps.flags & kInPath) && samplesLeft > 0 && !stopStarting) {
             samplesLeft--;
-            path_begin<COUNT>(P.cam, ps, ms, tileX0 + (lane & 7), tileY0 + (lane >> 3), c);
+            path_begin<COUNT>(P.cam, ps, ms, PT_PX, PT_PY, c);
             if (path_exhausted<INTEG>(ps, P.maxDepth)) path_finish(ps, acc, DEFER);
         }
         const bool hasExt = (ps.flags & kInPath) != 0;

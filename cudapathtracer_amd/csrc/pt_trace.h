@@ -791,7 +791,9 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
             if (win != last) {
                 const uint32_t tmin = (uint32_t)(a >> 32);
                 uint64_t tied = 0ull;
-                for (uint64_t rest = tmE; rest; rest &= rest - 1ull) {
+                const uint64_t mine = tmE;
+                const V3 invT = invE;
+                for (uint64_t rest = mine; rest; rest &= rest - 1ull) {
                     const int ti = __builtin_ctzll(rest);
                     const TriData q = load_tri<true>(S, C, ti);
                     float t, u, v;
@@ -807,8 +809,8 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
                     bool goLeft = inR == 0ull;
                     if (inL != 0ull && inR != 0ull) {
                         float tL, tR;
-                        slab(nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, eo, invE, tL);
-                        slab(nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, eo, invE, tR);
+                        slab(nd.a.x, nd.a.y, nd.a.z, nd.a.w, nd.b.x, nd.b.y, eo, invT, tL);
+                        slab(nd.b.z, nd.b.w, nd.c.x, nd.c.y, nd.c.z, nd.c.w, eo, invT, tR);
                         goLeft = tL < tR;
                     }
                     ref = goLeft ? f2i(nd.d.x) : f2i(nd.d.y);
@@ -923,10 +925,19 @@ struct Trav {
 // on entry (a dozen instructions per call against hundreds of node steps), the best t so far lives in the caller's Hit (h.t,
 // FLT_MAX until something is hit), and the shadow ray of a scene without MAT_LEAF triangles reports "occluded" in a flag bit
 // instead of a three-register throughput.
+#ifndef PT_RS_KEEP_INV
+#define PT_RS_KEEP_INV 0
+#endif
+#ifndef PT_OCCL_BOOL
+#define PT_OCCL_BOOL 0              // 1: "occluded" as a lane mask (an SGPR pair live through the traversal loops: the compiler then spills SGPRs INSIDE them, -3 % on scenes in HBM)
+#endif
 struct RayState {
     V3 o, d;
     float max_t;
     int32_t cur;
+#if PT_RS_KEEP_INV && !defined(PT_EXPERIMENTAL)
+    V3 inv;
+#endif
 #ifdef PT_EXPERIMENTAL
     V3 inv; float min_t;
     int32_t pend;                      // trace_resume_spec / trace_resume_q: the one postponed leaf (kRefNone = none)
@@ -944,6 +955,9 @@ PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasS
     r.o = hasShadow ? so : eo; r.d = hasShadow ? sd : ed;
     r.max_t = hasShadow ? smaxt : 999999.0f;
     r.cur = S.rootRef;
+#if PT_RS_KEEP_INV && !defined(PT_EXPERIMENTAL)
+    r.inv = inv3(r.d);
+#endif
 #ifdef PT_EXPERIMENTAL
     r.inv = inv3(r.d);
     r.min_t = 3.402823466e+38f;
@@ -959,10 +973,19 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
                          V3& thr, Hit& h, Ctr& c, Keep k = Keep{0, 0}) {
     typedef LoopExit<ONCHIP> X;
     if (!(r.flags & kRayBusy)) return;
+#if PT_RS_KEEP_INV
+    V3 o = r.o, d = r.d, inv = r.inv;
+#else
     V3 o = r.o, d = r.d, inv = inv3(r.d);
+#endif
     float max_t = r.max_t;
     int32_t cur = r.cur;
-    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true, occl = (r.flags & kRayOccluded) != 0;
+    bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+#if PT_OCCL_BOOL
+    bool occl = (r.flags & kRayOccluded) != 0;
+#else
+    uint32_t occlBits = r.flags & kRayOccluded;                    // a VGPR bit, not a lane mask in an SGPR pair through the loops
+#endif
     while (true) {
         // wave-level early exit: the lanes still here keep their state for the next call
         const int active = lanes_here();
@@ -1002,7 +1025,11 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
             if (isShadow) {
                 if (ok && (t < max_t)) {
                     uint32_t flags = f2u(q.e.w);
+#if PT_OCCL_BOOL
                     if (NOLEAF) { occl = true; occluded = true; break; }             // the caller reads kRayOccluded; thr is not touched
+#else
+                    if (NOLEAF) { occlBits = kRayOccluded; occluded = true; break; }
+#endif
                     if (!(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
                     // MAT_LEAF (integratorUtilities.cuh:218-239)
                     const PMat& m = S.mats[f2i(q.e.z)];
@@ -1029,7 +1056,14 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
         cur = (!occluded && st.sp > 0) ? st.template pop<ONCHIP>() : kRefNone;     // an occluded shadow ray ends here (BVHShadowRay returns)
     }
     r.o = o; r.d = d; r.max_t = max_t; r.cur = cur;
+#if PT_RS_KEEP_INV
+    r.inv = inv;
+#endif
+#if PT_OCCL_BOOL
     r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | (occl ? kRayOccluded : 0u);
+#else
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | occlBits;
+#endif
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }
 

@@ -117,6 +117,40 @@ def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
     share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1EEEvNS_7KParamsE"]        # megakernel<0, false, false, false, true, false, true>: 4-wave REFILL SIMPLE
     assert share["vgpr_count"] <= 128 and share["private_segment_fixed_size"] == 0 and share["vgpr_spill_count"] == 0, share
     hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
-    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 264, hbm
+    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 268, hbm
     gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0EEEvNS_7KParamsE"]                    # generic bounce, REFILL, 6 waves per SIMD
     assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 380, gen
+
+
+def _hot_loops(body):
+    """Innermost loops of a kernel that fetch a node or a triangle from global memory (>= 3 global_load_dwordx4, < 200 instructions):
+    (instructions, VALU, v_readlane / v_writelane, scratch instructions) per loop."""
+    lines = body.split("\n")
+    pos = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            pos[m.group(1)] = i
+    out = []
+    for i, ln in enumerate(lines):
+        m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if m and m.group(1) in pos and pos[m.group(1)] < i:
+            ins = [x.strip() for x in lines[pos[m.group(1)]:i + 1] if x.strip() and not x.strip().startswith((";", ".L"))]
+            if sum(1 for x in ins if x.startswith("global_load_dwordx4")) >= 3 and len(ins) < 200:
+                out.append((len(ins), sum(1 for x in ins if x.startswith("v_")), sum(1 for x in ins if "readlane" in x or "writelane" in x),
+                            sum(1 for x in ins if x.startswith("scratch_"))))
+    return out
+
+
+def test_traversal_loops_of_the_kernels_for_scenes_in_hbm_hold_no_spill_code(isa):
+    """The node loop and the triangle loop are where a scene in HBM spends its time (~65 VALU instructions per trip at a third of
+    the lanes). Round 3 learnt the hard way that a lane-varying `bool` kept across them becomes an SGPR pair, and that two more
+    live SGPR pairs made the compiler spill SGPRs INSIDE the loops (8 v_readlane / v_writelane per trip: -3 % on both scenes,
+    profiles/r03_ab_state_shrink.log) — state that crosses the loops lives in VGPR bits. No spill code of either kind in there."""
+    fns = _functions(isa)
+    for name in ("_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE", "_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0EEEvNS_7KParamsE",
+                 "_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1EEEvNS_7KParamsE"):
+        loops = _hot_loops(fns[name])
+        assert len(loops) >= 2, (name, loops)
+        assert all(ls == 0 and sc == 0 for (_, _, ls, sc) in loops), (name, loops)
+        assert min(n for (n, _, _, _) in loops) <= 120, (name, loops)          # the node loop: 116 instructions, 62 of them VALU
