@@ -339,7 +339,14 @@ PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& 
     // (a fresh record, not a copy of the previous bounce's: whatever the last bounce recorded was consumed — the shadow ray
     // started, the term applied — before this bounce runs, so the old values are dead here and not live across the traversal)
     NeeRecord nr;
+#ifndef PT_NR_FRESH
+#define PT_NR_FRESH 1
+#endif
+#if PT_NR_FRESH
     nr.so = v3(0.0f); nr.sd = v3(0.0f); nr.smaxt = 0.0f; nr.neeRaw = v3(0.0f); nr.neeBeta = v3(0.0f); nr.neeW = 0.0f;
+#else
+    nr.so = ps.so; nr.sd = ps.sd; nr.smaxt = ps.smaxt; nr.neeRaw = ps.neeRaw; nr.neeBeta = ps.neeBeta; nr.neeW = ps.neeW;
+#endif
     bool done = bounce_core<INTEG, COUNT, DEFER, SIMPLE>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
                                                  ms, h, maxDepth, useMIS, shadow, c);
     ps.rng = rng;
