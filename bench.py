@@ -96,17 +96,18 @@ def _tf(b):
 def kernel_name(flags, variant):
     if variant != "megakernel":
         return "pt::wf_logic_kernel + pt::wf_trace_kernel (all launches of one frame)"
+    lean = _tf(flags.get("lean", False))
     if flags["hbm_kernel"]:
         if flags.get("simple"):
             return "pt::megakernel_hbm_simple<0>"
-        return "pt::megakernel_hbm<0, false, %s, %s, false>" % (_tf(flags["culling"]), _tf(flags["refill"]))
+        return "pt::megakernel_hbm<0, false, %s, %s, false, %s>" % (_tf(flags["culling"]), _tf(flags["refill"]), lean)
     if flags.get("simple") and not flags["onchip"]:
-        return "pt::megakernel<0, false, false, false, true, false, true, 1>"              # small shares of a diffuse-only scene in HBM
+        return "pt::megakernel<0, false, false, false, true, false, true, 1, false>"       # small shares of a diffuse-only scene in HBM
     if flags.get("flat_pair"):
-        return "pt::megakernel_flat2<0, %s>" % _tf(flags.get("simple", False))
+        return "pt::megakernel_flat2<0, %s, %s>" % (_tf(flags.get("simple", False)), lean)
     if flags.get("simple"):
-        return "pt::megakernel<0, false, false, true, false, true, true, 1>"
-    return "pt::megakernel<0, false, false, %s, %s, %s, false, 1>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]))
+        return "pt::megakernel<0, false, false, true, false, true, true, 1, false>"
+    return "pt::megakernel<0, false, false, %s, %s, %s, false, 1, %s>" % (_tf(flags["onchip"]), _tf(flags["refill"]), _tf(flags["flat"]), lean)
 
 
 def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):

@@ -447,7 +447,7 @@ class Scene:
 
     def flags(self):
         f = lib().pt_scene_flags(self.h)
-        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64), "simple": bool(f & 128), "flat_pair": bool(f & 256), "leaf_table": bool(f & 512)}
+        return {"onchip": bool(f & 1), "persistent": bool(f & 2), "time_slices": bool(f & 4), "hbm_kernel": bool(f & 8), "culling": bool(f & 16), "refill": bool(f & 32), "flat": bool(f & 64), "simple": bool(f & 128), "flat_pair": bool(f & 256), "leaf_table": bool(f & 512), "lean": bool(f & 1024)}
 
     def tile_handovers(self):
         """pt_last_tile_handovers: tiles that changed hands between waves in the last (completed) megakernel launch."""

@@ -79,6 +79,8 @@ struct pt_scene {
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
     bool noLeafTris = false;                      // no triangle carries a MAT_LEAF material: a shadow ray is occluded by any hit (order-free)
+    bool leanOk = false, leanWanted = true;       // scene qualifies for the LEAN generic bounce (no MAT_LEAF triangle, no texture / transmission map on any triangle's material) / "lean" 0 turns it off (A/B)
+    int lastLaunchLean = 0;
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
     bool flatOk = false; int flatWanted = 1;      // "flat": 0 off, 1 (or 2) on: scenes of at most 128 nodes / triangles (64- or 128-bit masks)   // scene qualifies for the FLAT kernels (checked in repack) / "flat" 0 turns them off (A/B)
     int lastLaunchFlat = 0, lastLaunchSimple = 0, lastLaunchLeafTable = 0;
@@ -367,6 +369,12 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
             noLeaf = id >= 0 && id < d->n_materials && d->materials[id].type != PT_MAT_LEAF;
         }
         s->noLeafTris = noLeaf;
+        bool lean = noLeaf;                       // LEAN (pt_shade.h): additionally no triangle's material samples a texture
+        for (int i = 0; i < nT && lean; i++) {
+            const pt_material& m = d->materials[d->triangles[i].materialID];
+            lean = !m.hasTexture && !m.hasTransMap;
+        }
+        s->leanOk = lean;
     }
     if (!onDevice) {
         if (int r = upload(s->nodes, nodes.data(), nodes.size() * sizeof(PNode))) return r;
@@ -816,6 +824,10 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     // the instantiations that have the SIMPLE bounce: FLAT, the production kernel for scenes in HBM and its 4-wave form (small shares)
     P.simple = ((P.flat && s->simpleOk && s->simpleWanted) || simpleHbm) ? 1 : 0;
     if (P.flat == 1 && s->noLeafTris && !s->armless && s->flat2Wanted && integrator == PT_UNIDIRECTIONAL && !count && useMIS) P.flat = 3;   // ... and the pair form of FLAT
+    // the LEAN generic bounce exists for the three timed kernels generic scenes run: the pair form of FLAT, the kernel for scenes in HBM
+    // and its 4-wave form (both REFILL)
+    P.lean = (s->leanOk && s->leanWanted && !s->armless && !P.simple && !count && !P.cull && (P.flat == 3 || (!onchip && P.refill))) ? 1 : 0;
+    s->lastLaunchLean = P.lean;
     s->lastLaunchRefill = P.refill; s->lastLaunchFlat = (P.flat && !count) ? 1 : 0;
     s->lastLaunchSimple = (P.simple && !count) ? 1 : 0;
     s->lastLaunchFlat2 = (P.flat == 3) ? 1 : 0;
@@ -1026,7 +1038,7 @@ const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
     {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1}, {"wide", 0, 1},
-    {"compact", 0, 1}, {"wf_wide_wg", 0, 2},
+    {"compact", 0, 1}, {"wf_wide_wg", 0, 2}, {"lean", 0, 1},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -1070,6 +1082,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 19: s->wideWanted = v != 0; break;
         case 20: s->compactWanted = v != 0; break;
         case 21: s->wfWideWg = v; break;
+        case 22: s->leanWanted = v != 0; break;
     }
     return 0;
 }
@@ -1099,6 +1112,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 19: *out = s->wideWanted; break;
         case 20: *out = s->compactWanted; break;
         case 21: *out = s->wfWideWg; break;
+        case 22: *out = s->leanWanted; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;
@@ -1110,7 +1124,7 @@ int pt_scene_flags(pt_scene* s) {
     const bool pers = s->persistent && !s->xcdBands;
     // the kernel the last launch used; before any launch, the one a full 1080p-class frame would get
     const bool hbm = s->lastLaunchHbm >= 0 ? s->lastLaunchHbm == 1 : (!onchip && !(s->deferShadow && !s->armless) && s->wavesHbmOk);
-    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0) | (s->lastLaunchFlat2 ? 256 : 0) | (s->lastLaunchLeafTable ? 512 : 0);
+    return (onchip ? 1 : 0) | (pers ? 2 : 0) | ((pers && s->sliceIters > 0) ? 4 : 0) | (hbm ? 8 : 0) | ((s->cull && hbm) ? 16 : 0) | (s->lastLaunchRefill ? 32 : 0) | (s->lastLaunchFlat ? 64 : 0) | (s->lastLaunchSimple ? 128 : 0) | (s->lastLaunchFlat2 ? 256 : 0) | (s->lastLaunchLeafTable ? 512 : 0) | (s->lastLaunchLean ? 1024 : 0);
 }
 
 float pt_last_kernel_ms(pt_scene* s) {

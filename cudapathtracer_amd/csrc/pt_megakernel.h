@@ -138,8 +138,13 @@ PT_DEV void state_store(uint32_t* p, uint32_t v, bool shared) { if (shared) PT_Q
 // INTEG: 0 = Li_unidirectional, 2 = Li_naive_unidirectional. DEFER: see pt_path.h. ONCHIP: the whole packed
 // scene is in the LDS cache and the stack never spills (pt_trace.h); the host decides per scene. STACKN: LDS
 // stack entries per lane. The body is shared by the two kernels below, which differ in their register cap.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, int TREE = 0>
+// LEAN: the generic bounce for scenes without MAT_LEAF triangles and without textures (pt_shade.h).
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, int STACKN, bool CULL = false, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, int TREE = 0, bool LEAN = false>
 PT_DEV void megakernel_body(const KParams& P) {
+    // NOLEAF: no triangle of the scene carries a MAT_LEAF material, so a shadow ray's throughput is exactly 0 or 1 — one flag bit
+    // of the resumable traversal, and the DEFER record holds the finished NEE term (PRE). True for SIMPLE and LEAN scenes and
+    // for every scene the pair form of FLAT is launched on (pt_api.hip: noLeafTris).
+    constexpr bool NOLEAF = SIMPLE || LEAN || (DEFER && FLAT);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
     // ONCHIP kernels: the host guarantees that the bounce's records fit as well (pt_api.hip: `onchip`), so their address
@@ -255,10 +260,10 @@ PT_DEV void megakernel_body(const KParams& P) {
 #endif
     auto shadowSync = [&](V3 ro, V3 wi, float maxt) {
         PT_STAMP(2);
-        V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+        V3 t_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE || LEAN>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
 #ifdef PT_DIAG_DOUBLE_SHADOW        // cost measurement only (tools/phase_cost.sh): the shadow ray traced twice, same result
         {
-            const V3 t2_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
+            const V3 t2_ = trace_shadow<COUNT, STACKN, ONCHIP, CULL, SIMPLE || LEAN>(S, SC, ro, wi, maxt, st, c, Keep{P.nodeKeep, P.triKeep});
             t_ = v3(fminf_(t_.x, t2_.x), fminf_(t_.y, t2_.y), fminf_(t_.z, t2_.z));
         }
 #endif
@@ -318,10 +323,10 @@ PT_DEV void megakernel_body(const KParams& P) {
             // Lanes whose rays are done take their logic step (DEFER form: the shadow ray is recorded, not traced
             // inside the bounce) and start their next pair of rays; lanes still tracing skip it and resume below.
             if (!(rs.flags & kRayBusy)) {
-                if constexpr (SIMPLE) thr = (rs.flags & kRayOccluded) ? v3(0.0f) : v3(1.0f);      // NOLEAF: the shadow ray's result is one flag bit (pt_trace.h: RayState)
-                apply_pending<SIMPLE>(ps, thr, acc);
+                if constexpr (NOLEAF) thr = (rs.flags & kRayOccluded) ? v3(0.0f) : v3(1.0f);      // the shadow ray's result is one flag bit (pt_trace.h: RayState)
+                apply_pending<NOLEAF>(ps, thr, acc);
                 if (ps.flags & kInPath) {
-                    bool done = path_bounce<INTEG, COUNT, true, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+                    bool done = path_bounce<INTEG, COUNT, true, SIMPLE, LEAN, NOLEAF>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
                     if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
                     if (done) path_finish(ps, acc, true);
                 }
@@ -372,7 +377,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             }
 #endif
 #if !defined(PT_EXPERIMENTAL)
-            trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
             if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
             else trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
@@ -384,9 +389,9 @@ PT_DEV void megakernel_body(const KParams& P) {
             PT_STAMP(1);
             continue;
         }
-        if (DEFER) apply_pending<SIMPLE>(ps, thr, acc);
+        if (DEFER) apply_pending<NOLEAF>(ps, thr, acc);
         if (ps.flags & kInPath) {
-            bool done = path_bounce<INTEG, COUNT, DEFER, SIMPLE>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
+            bool done = path_bounce<INTEG, COUNT, DEFER, SIMPLE, LEAN, NOLEAF>(S, ps, ms, h, P.maxDepth, P.useMIS, shadowSync, c);
             if (!done) done = path_exhausted<INTEG>(ps, P.maxDepth);
             if (done) path_finish(ps, acc, DEFER);
         }
@@ -486,27 +491,27 @@ PT_DEV void megakernel_body(const KParams& P) {
 // included (5: +10 %, 7-8: no better). Both run the same body.
 // LDS-resident scenes run in workgroups of 4, 8 or 16 waves (the host picks the smallest whose LDS share holds the scene:
 // one copy of the scene per workgroup), hence the launch bound of 1024 for ONCHIP kernels; 4 waves per SIMD either way.
-template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1>
+template <int INTEG, bool COUNT, bool DEFER, bool ONCHIP, bool REFILL = false, bool FLAT = false, bool SIMPLE = false, int FLATW = 1, bool LEAN = false>
 __global__ void __launch_bounds__(ONCHIP ? 1024 : 256)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))     // cap VGPRs so that PT_MIN_WAVES waves fit per SIMD
 #endif
-megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT, SIMPLE, FLATW>(P); }
+megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, false, REFILL, FLAT, SIMPLE, FLATW, 0, LEAN>(P); }
 
-template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false>
+template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false, bool LEAN = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
-megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE>(P); }
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE, 1, 0, LEAN>(P); }
 
 // FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): scenes of at most 64 nodes / triangles none of which is a MAT_LEAF
 // (any hit occludes a shadow ray) and all of whose materials have a dispatch arm (the DEFER logic step is exact), MIS
 // integrator; with the SIMPLE bounce where the scene allows. The wave's "stack" area is the 25 x 64-word scratch of the tests.
 constexpr int kStackFlat2 = 25;
-template <int INTEG, bool SIMPLE>
+template <int INTEG, bool SIMPLE, bool LEAN = false>
 __global__ void __launch_bounds__(1024)
 #if PT_MIN_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(PT_MIN_WAVES)))
 #endif
-megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, SIMPLE, 1>(P); }
+megakernel_flat2(KParams P) { megakernel_body<INTEG, false, true, true, kStackFlat2, false, false, true, SIMPLE, 1, 0, LEAN>(P); }
 
 #ifdef PT_EXPERIMENTAL
 // ... and the same on the reference tree collapsed to 4-wide nodes (pt_trace_experimental.h: trace_resume_w4).

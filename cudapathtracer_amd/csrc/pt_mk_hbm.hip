@@ -23,10 +23,13 @@ hipError_t launch_megakernel_hbm(int integrator, bool count, bool syncShadow, bo
                                  else PT_LAUNCH_HBM_TREES(I, C) \
                                  if (P.refill && P.simple && !C) { PT_LDS_OK((megakernel_hbm_simple<I>)); \
                                                                    hipLaunchKernelGGL((megakernel_hbm_simple<I>), grid, block, lds, stream, P); } \
+                                 else if (P.refill && P.lean && !C) { PT_LDS_OK((megakernel_hbm<I, false, false, true, false, true>)); \
+                                                                      hipLaunchKernelGGL((megakernel_hbm<I, false, false, true, false, true>), grid, block, lds, stream, P); } \
                                  else if (P.refill) PT_LAUNCH_HBM1(I, C, false, true); \
                                  else PT_LAUNCH_HBM1(I, C, false, false); } while (0)
 #define PT_PICK(I) do { if (hbm) { if (count) PT_LAUNCH_HBM(I, true); else PT_LAUNCH_HBM(I, false); } \
                         else if (P.refill && P.simple && !count) hipLaunchKernelGGL((megakernel<I, false, false, false, true, false, true>), grid, block, lds, stream, P); \
+                        else if (P.refill && P.lean && !count) hipLaunchKernelGGL((megakernel<I, false, false, false, true, false, false, 1, true>), grid, block, lds, stream, P); \
                         else if (P.refill) { if (count) PT_LAUNCH_MK(I, true, false, true); else PT_LAUNCH_MK(I, false, false, true); } \
                         else if (count) PT_LAUNCH_MK(I, true, false, false); \
                         else PT_LAUNCH_MK(I, false, false, false); } while (0)

@@ -12,6 +12,7 @@ hipError_t launch_megakernel_lds(int integrator, bool count, const KParams& P, d
 #define PT_LAUNCH(I, C, RF, FL) do { PT_LDS_OK((megakernel<I, C, false, true, RF, FL>)); hipLaunchKernelGGL((megakernel<I, C, false, true, RF, FL>), grid, block, lds, stream, P); } while (0)
     if (P.flat == 3 && integrator == 0 && !count) {          // both rays of a lane in one FLAT pass (SIMPLE scenes, MIS)
         if (P.simple) { PT_LDS_OK((megakernel_flat2<0, true>)); hipLaunchKernelGGL((megakernel_flat2<0, true>), grid, block, lds, stream, P); }
+        else if (P.lean) { PT_LDS_OK((megakernel_flat2<0, false, true>)); hipLaunchKernelGGL((megakernel_flat2<0, false, true>), grid, block, lds, stream, P); }
         else { PT_LDS_OK((megakernel_flat2<0, false>)); hipLaunchKernelGGL((megakernel_flat2<0, false>), grid, block, lds, stream, P); }
         return hipGetLastError();
     }

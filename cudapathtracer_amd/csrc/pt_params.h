@@ -79,6 +79,7 @@ struct KParams {
     int cull;                      // opt-in box culling (pt_trace.h: CULL); only the kernel for scenes in HBM has the instantiation
     int triKeep;                   // ... and its triangle loop once no more than entered * triKeep / 16 lanes still have triangles in their leaf
     int nodeKeep;                  // a wave leaves its node loop once no more than active * nodeKeep / 16 lanes are still descending (pt_trace.h); 0 = when none is
+    int lean;                      // 1: the LEAN instantiation of the generic bounce — no MAT_LEAF triangle, no textures (pt_shade.h); timed launches of the REFILL / pair kernels
     int simple;                    // 1 (with flat): the SIMPLE instantiation — every triangle an untextured, non-boundary MAT_DIFFUSE in non-absorbing air (pt_path.h)
     int flat;                      // 1: the FLAT instantiation (pt_trace.h: trace_closest_flat) — LDS-resident scenes with at most 64 internal nodes / 64 triangles
     int refill;                    // 1: the REFILL instantiation (pt_trace.h: trace_resume) — finished lanes shade and come back while the rest keep tracing

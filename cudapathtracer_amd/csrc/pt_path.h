@@ -153,7 +153,9 @@ struct NeeRecord { V3 so, sd; float smaxt; V3 neeRaw, neeBeta; float neeW; };
 // that is neither a boundary nor specular, and material 0 (the air every path starts in) does not absorb — the reference's
 // own Cornell configuration. Then the medium stack only ever holds air, every hit is a true hit, the three dispatchers
 // have one arm each, and all of that is known at compile time: same values, a third of the code.
-template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE, class MS, class ShadowFn>
+// LEAN: see pt_shade.h (no MAT_LEAF triangle, no textures). PRE: the DEFER record holds the finished NEE term (apply_pending<PRE>)
+// — valid when no triangle is a MAT_LEAF: SIMPLE and LEAN scenes, and every scene the pair form of FLAT accepts.
+template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE, bool LEAN, bool PRE, class MS, class ShadowFn>
 PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, V3& Li, V3& prevPoint, V3& woLocal,
                         float& pdf, float& etaI, float& etaT, int& depth, int& msTop, uint32_t& flags, NeeRecord& nr,
                         MS& ms, const Hit& h, int maxDepth, int useMIS, ShadowFn shadow, Ctr& c) {
@@ -172,7 +174,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         V3 f = v3(0.0f), toNext = v3(0.0f);
         float p = 0.0f;
         if (SIMPLE) cosine_sample_f<COUNT>(rng, ld3(m.albedo), toNext, f, p, c, m.albedoOverPi);
-        else sample_f_eval<COUNT>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
+        else sample_f_eval<COUNT, LEAN>(rng, m, S.textures, toSurface, 1.0f, hi.backface, toNext, f, p, hi.uvx, hi.uvy, c);
         if (p <= 0.0f || dot(f, f) < kEps) return true;
         Li = Li + hi.emission * beta;
         beta = beta * ((f * __builtin_fabsf(toNext.z)) / p);
@@ -276,15 +278,15 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
                 float lightPdf = dist2 / (cosL * (float)S.nLights * L.area);
                 V3 wiL = to_local(wi, frame);
                 if (!DEFER) woLocal = wiL;
-                V3 f = SIMPLE ? ld3(m.albedoOverPi) : f_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
+                V3 f = SIMPLE ? ld3(m.albedoOverPi) : f_eval<LEAN>(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy);
                 V3 nee = ((f * ld3(L.emission)) * cosS) / lightPdf;
                 if (lightPdf > kEps) {
                     float pdfB = pdf;
                     if (SIMPLE) pdfB = cosine_pdf(wiL);
-                    else pdf_eval(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy, pdfB);
+                    else pdf_eval<LEAN>(m, S.textures, wiLocal, wiL, etaI, hi.uvx, hi.uvy, pdfB);
                     float wN = lightPdf * lightPdf / (pdfB * pdfB + lightPdf * lightPdf);
                     if (DEFER) {
-                        if (SIMPLE) nr.neeRaw = (beta * nee) * wN;            // apply_pending<PRE>: the finished term (thr is exactly 1 when it is added)
+                        if (PRE) nr.neeRaw = (beta * nee) * wN;               // apply_pending<PRE>: the finished term (thr is exactly 1 when it is added)
                         else { nr.neeRaw = nee; nr.neeBeta = beta; nr.neeW = wN; }
                         flags |= kNeeValid;
                     } else {
@@ -298,7 +300,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
         }
         V3 f = v3(0.0f);
         if (SIMPLE) cosine_sample_f<COUNT>(rng, ld3(m.albedo), woLocal, f, pdf, c, m.albedoOverPi);
-        else sample_f_eval<COUNT>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
+        else sample_f_eval<COUNT, LEAN>(rng, m, S.textures, wiLocal, etaI, hi.backface, woLocal, f, pdf, hi.uvx, hi.uvy, c);
         V3 woWorld = to_world(woLocal, frame);
         pdf = fmaxf_(pdf, 0.01f);
         if (!SIMPLE && woLocal.z < 0.0f) {                 // (a cosine-sampled direction has z = sqrt(1 - u1) > 0: never taken when SIMPLE)
@@ -329,7 +331,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
 }
 
 
-template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE = false, class MS, class ShadowFn>
+template <int INTEG, bool COUNT, bool DEFER, bool SIMPLE = false, bool LEAN = false, bool PRE = SIMPLE, class MS, class ShadowFn>
 PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& h, int maxDepth, int useMIS, ShadowFn shadow, Ctr& c) {
     Rng rng = ps.rng;
     V3 o = ps.o, d = ps.d, beta = ps.beta, Li = ps.Li, prevPoint = ps.prevPoint, woLocal = ps.woLocal;
@@ -347,7 +349,7 @@ PT_DEV bool path_bounce(const DeviceScene& S, PathState& ps, MS& ms, const Hit& 
 #else
     nr.so = ps.so; nr.sd = ps.sd; nr.smaxt = ps.smaxt; nr.neeRaw = ps.neeRaw; nr.neeBeta = ps.neeBeta; nr.neeW = ps.neeW;
 #endif
-    bool done = bounce_core<INTEG, COUNT, DEFER, SIMPLE>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
+    bool done = bounce_core<INTEG, COUNT, DEFER, SIMPLE, LEAN, PRE>(S, rng, o, d, beta, Li, prevPoint, woLocal, pdf, etaI, etaT, depth, msTop, flags, nr,
                                                  ms, h, maxDepth, useMIS, shadow, c);
     ps.rng = rng;
     ps.o = o; ps.d = d; ps.beta = beta; ps.Li = Li; ps.prevPoint = prevPoint; ps.woLocal = woLocal;

@@ -225,8 +225,13 @@ PT_DEV void leaf_sample_f(Rng& rng, V3 wi, float ior, float currIOR, float rough
     pdf = leaf_pdf(ior, currIOR, roughness, transmission, wi, wo);
 }
 
+// LEAN (chosen per scene by the host, pt_api.hip): no triangle's material is a MAT_LEAF and none has a texture or a
+// transmission map — Cornell boxes of glass, mirrors and metals, a glass blob. The leaf arms (the largest of the five) and the
+// bilinear texture fetch are then dead code, known at compile time: same values, a third less code and fewer live registers.
+template <bool LEAN = false>
 PT_DEV void material_inputs(const PMat& m, const float4* tex, float uvx, float uvy, bool wantAlbedo, V3& albedo, float& trans) {
     albedo = ld3(m.albedo);
+    if (LEAN) { trans = m.transmission; return; }
     if (wantAlbedo && (m.flags & kMatHasTexture)) sample_texture(m, tex, uvx, uvy, albedo);
     trans = m.transmission;
     if (m.flags & kMatHasTransMap) {       // sampled through the albedo texture's start/size (reflectors.cuh:558-562)
@@ -238,34 +243,36 @@ PT_DEV void material_inputs(const PMat& m, const float4* tex, float uvx, float u
 
 // f_eval, reflectors.cuh:547-584. wi points INTO the surface (negated inside). MAT_DIFFUSE uses
 // mat.albedo, not the sampled texture (:566); dielectrics and unknown types leave f at 0.
+template <bool LEAN = false>
 PT_DEV V3 f_eval(const PMat& m, const float4* tex, V3 wi, V3 wo, float etaI, float uvx, float uvy) {
     V3 albedo; float trans;
-    material_inputs(m, tex, uvx, uvy, true, albedo, trans);
+    material_inputs<LEAN>(m, tex, uvx, uvy, true, albedo, trans);
     if (m.type == 0) return ld3(m.albedoOverPi);                 // cosine_f(mat.albedo) = albedo / PI, divided once at scene set-up (same IEEE division)
     if (m.type == 1) return microfacet_metal_f(ld3(m.eta), ld3(m.k), m.roughness, -wi, wo);
-    if (m.type == 4) return leaf_f(albedo, m.ior, etaI, m.roughness, trans, -wi, wo);
+    if (!LEAN && m.type == 4) return leaf_f(albedo, m.ior, etaI, m.roughness, trans, -wi, wo);
     if (m.type == 6) return v3(1.0f / fmaxf_(wo.z, kEps));           // mirror_f :59-63
     return v3(0.0f);
 }
 
 // pdf_eval, reflectors.cuh:633-666. Returns false when no arm writes `pdf` (it then keeps its old value).
+template <bool LEAN = false>
 PT_DEV bool pdf_eval(const PMat& m, const float4* tex, V3 wi, V3 wo, float etaI, float uvx, float uvy, float& pdf) {
     V3 albedo; float trans;
-    material_inputs(m, tex, uvx, uvy, false, albedo, trans);
+    material_inputs<LEAN>(m, tex, uvx, uvy, false, albedo, trans);
     if (m.type == 0) { pdf = cosine_pdf(wo); return true; }
     if (m.type == 1) { pdf = microfacet_pdf(m.roughness, -wi, wo); return true; }
     if (m.type == 2) { pdf = 0.0f; return true; }
-    if (m.type == 4) { pdf = leaf_pdf(m.ior, etaI, m.roughness, trans, -wi, wo); return true; }
+    if (!LEAN && m.type == 4) { pdf = leaf_pdf(m.ior, etaI, m.roughness, trans, -wi, wo); return true; }
     if (m.type == 6) { pdf = 1.0f; return true; }
     return false;
 }
 
 // sample_f_eval, reflectors.cuh:588-629. Types without an arm leave wo / f / pdf untouched.
-template <bool COUNT>
+template <bool COUNT, bool LEAN = false>
 PT_DEV void sample_f_eval(Rng& rng, const PMat& m, const float4* tex, V3 wi, float etaI, bool backface, V3& wo, V3& f, float& pdf, float uvx, float uvy, Ctr& c) {
     V3 albedo; float trans;
-    material_inputs(m, tex, uvx, uvy, true, albedo, trans);
-    if (m.type == 0) cosine_sample_f<COUNT>(rng, albedo, wo, f, pdf, c, (m.flags & kMatHasTexture) ? nullptr : m.albedoOverPi);
+    material_inputs<LEAN>(m, tex, uvx, uvy, true, albedo, trans);
+    if (m.type == 0) cosine_sample_f<COUNT>(rng, albedo, wo, f, pdf, c, (!LEAN && (m.flags & kMatHasTexture)) ? nullptr : m.albedoOverPi);
     else if (m.type == 1) {                                                                       // :160-180
         V3 w = -wi;
         V3 h = ggx_sample_h<COUNT>(rng, m.roughness, c);
@@ -274,7 +281,7 @@ PT_DEV void sample_f_eval(Rng& rng, const PMat& m, const float4* tex, V3 wi, flo
         f = microfacet_metal_f(ld3(m.eta), ld3(m.k), m.roughness, w, wo);
         pdf = microfacet_pdf(m.roughness, w, wo);
     } else if (m.type == 2) dielectric_sample_f<COUNT>(rng, -wi, m.ior, backface, wo, f, pdf, c);
-    else if (m.type == 4) leaf_sample_f<COUNT>(rng, -wi, m.ior, etaI, m.roughness, albedo, trans, wo, f, pdf, c);
+    else if (!LEAN && m.type == 4) leaf_sample_f<COUNT>(rng, -wi, m.ior, etaI, m.roughness, albedo, trans, wo, f, pdf, c);
     else if (m.type == 6) {                                                                       // :70-76
         V3 w = -wi;
         wo = v3(-w.x, -w.y, w.z);

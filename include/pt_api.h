@@ -187,7 +187,7 @@ int pt_last_tile_handovers(pt_scene* scene);
  * (every triangle an untextured MAT_DIFFUSE: one arm per dispatcher, no medium stack), bit 8 = the pair form of FLAT
  * (shadow + extension ray in one pass), bit 9 = the FLAT launch decided the visited leaves from the leaves' own boxes (the
  * scene's boxes are finite and nested, checked at pt_scene_create; a caller's loose or refit tree takes the lockstep walk
- * over the boxes as given). For labelling measurements. */
+ * over the boxes as given), bit 10 = it used the LEAN generic bounce. For labelling measurements. */
 int pt_scene_flags(pt_scene* scene);
 /* Opt-in (default off): skip BVH children whose box lies beyond the best hit so far / beyond a shadow ray's max_t.
  * The reference has no such test and its results are the contract, so the default kernels do not have it either: a
@@ -207,6 +207,8 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "flat2" 0|1           FLAT scenes (<= 64 triangles, no MAT_LEAF triangle), MIS integrator: shadow ray and next extension
  *                         ray in one FLAT pass (1)
  *   "simple" 0|1          with FLAT: the diffuse-only bounce for scenes whose triangles are all untextured MAT_DIFFUSE (1)
+ *   "lean" 0|1            the generic bounce without its leaf arms and texture fetches for scenes that have neither a MAT_LEAF
+ *                         triangle nor a textured material — glass, mirrors, metals (1)
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
  *   "refill" 0|1          resumable traversal for scenes in HBM (1)

@@ -674,7 +674,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 10, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0, "wf_wide_wg": 1}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0, "wf_wide_wg": 1, "lean": 1}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
@@ -710,7 +710,7 @@ def _render_window(api, sc, cam, w, h, spp, md, rect, counters=False, integrator
     return col[y0:y1, x0:x1], (cnt[y0:y1, x0:x1] if counters else None)
 
 
-@pytest.mark.parametrize("mode", ["production", "generic_bounce", "plain_loops_4wave", "counted", "wavefront", "compact"])
+@pytest.mark.parametrize("mode", ["production", "generic_bounce", "generic_bounce_all_arms", "plain_loops_4wave", "counted", "wavefront", "compact"])
 @pytest.mark.parametrize("case", window_cases())
 def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, mode):
     """BASELINE C3 / C4 / C5 geometry and depth at the 1080p camera, against the oracle: 64x64 windows of the 82 k-triangle
@@ -725,7 +725,7 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
     assert s["sha256"] == str(g["scene_sha256"])
     hs = api.HostScene(s["config"])
     w, h, spp, md, integ = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]), int(g["integrator"])
-    opts = {"production": {"waves_hbm": 2}, "generic_bounce": {"waves_hbm": 2, "simple": 0}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
+    opts = {"production": {"waves_hbm": 2}, "generic_bounce": {"waves_hbm": 2, "simple": 0}, "generic_bounce_all_arms": {"waves_hbm": 2, "simple": 0, "lean": 0}, "plain_loops_4wave": {"waves_hbm": 0, "refill": 0, "node_keep": 0, "tri_keep": 0},
             "counted": {"waves_hbm": 2}, "wavefront": {"wf_wide_wg": 2}, "compact": {"waves_hbm": 2, "compact": 1}}[mode]
     sc = api.Scene(hs, options=opts)
     if mode == "wavefront":
@@ -736,10 +736,11 @@ def test_real_scene_windows_vs_oracle(api, oracle, gpu_ready, scene_dir, case, m
         assert_bits_equal(col, g["colors"][k], "%s window %d (%s)" % (case, k, mode))
         if mode == "counted":
             assert np.array_equal(cnt, g["counters"][k]), (case, k)
-        if mode in ("production", "generic_bounce", "compact"):
+        if mode in ("production", "generic_bounce", "generic_bounce_all_arms", "compact"):
             fl = sc.flags()
             assert fl["hbm_kernel"] and fl["refill"] and not fl["onchip"] and not fl["culling"], fl
-            assert fl["simple"] == (mode != "generic_bounce"), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
+            assert fl["simple"] == (not mode.startswith("generic_bounce")), fl          # both scenes are diffuse-only: the SIMPLE bounce is what production runs
+            assert fl["lean"] == (mode == "generic_bounce"), fl                         # ... and without it the generic bounce drops its leaf / texture arms (no such material here)
     x0, y0, x1, y1 = (int(v) for v in g["rects"][1])
     ocol, ocnt, _ = oracle.OracleScene(s["config"]).render(rect=(x0, y0, x1, y1), counters=True, threads=8, integrator=integ)
     assert_bits_equal(ocol[y0:y1, x0:x1], g["colors"][1], "fixture == live oracle")
@@ -759,7 +760,8 @@ def _oracle_tile(osc, w, h, spp, md, x0, y0, integrator=0):
         return np.stack(list(ex.map(row, range(8))))
 
 
-@pytest.mark.parametrize("config", ["C2_cornell_1024spp_depth8", "C3_blob82k_1024spp_depth8", "C4_atrium263k_4096spp_depth16", "C3_blob82k_naive_1024spp_depth8"])
+@pytest.mark.parametrize("config", ["C2_cornell_1024spp_depth8", "C3_blob82k_1024spp_depth8", "C4_atrium263k_4096spp_depth16", "C3_blob82k_naive_1024spp_depth8",
+                                    "mixed_cornell_1024spp_depth8", "glass_blob82k_256spp_depth8"])
 def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_ready, scene_dir, config):
     """The reference carries ONE XORWOW stream per pixel through all samples of a render (state reloaded and stored around every
     sample, deviceCode.cu:294, 541, 568-573). The window fixtures stop at 4 spp; here ONE 8x8 tile (pt_tile_range of one tile)
@@ -773,9 +775,13 @@ def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_r
         "C3_blob82k_1024spp_depth8": ("blob_in_box", dict(spp=1024, max_depth=8), (1088, 640), {"waves_hbm": 2}, 0),   # the blob's silhouette
         "C4_atrium263k_4096spp_depth16": ("atrium", dict(spp=4096, max_depth=16), (960, 536), {"waves_hbm": 2}, 0),
         "C3_blob82k_naive_1024spp_depth8": ("blob_in_box", dict(spp=1024, max_depth=8), (896, 480), {"waves_hbm": 2}, 2),
+        # the general bounce (bench.py's secondary workloads): mirror / glass with nested water / GGX gold on the glass box's edge; the glass blob
+        "mixed_cornell_1024spp_depth8": ("cornell", dict(spp=1024, max_depth=8, tall_material=19, short_material=5, nested=True, extra_boxes=1, extra_materials=[4]),
+                                         (1112, 624), {}, 0),
+        "glass_blob82k_256spp_depth8": ("blob_in_box", dict(spp=256, max_depth=8, material=5), (1088, 640), {"waves_hbm": 2}, 0),
     }[config]
     w, h = 1920, 1080
-    s = getattr(scenes, gen)(os.path.join(scene_dir, "deep_" + gen), width=w, height=h, name="deep_" + gen, **kw)
+    s = getattr(scenes, gen)(os.path.join(scene_dir, "deep_" + config), width=w, height=h, name="deep_" + gen, **kw)
     hs = api.HostScene(s["config"])
     sc = api.Scene(hs, options=opts)
     x0, y0 = tile_xy
@@ -783,7 +789,9 @@ def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_r
     col = np.zeros((h, w, 4), np.float32)
     sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"], tiles=api.TileRange(tile, 1, 1), out=col, integrator=integ)
     fl = sc.flags()
-    assert fl["time_slices"] and (fl["flat_pair"] if gen == "cornell" else (fl["hbm_kernel"] and fl["simple"] and fl["refill"])), fl
+    generic = config.startswith(("mixed", "glass"))
+    assert fl["lean"] == generic, fl
+    assert fl["time_slices"] and (fl["flat_pair"] if gen == "cornell" else (fl["hbm_kernel"] and fl["refill"])) and fl["simple"] == (not generic), fl
     assert sc.tile_handovers() >= 4, sc.tile_handovers()          # the one tile's state really travelled between waves
     want = _oracle_tile(oracle.OracleScene(s["config"]), w, h, kw["spp"], kw["max_depth"], x0, y0, integ)
     got = col[y0:y0 + 8, x0:x0 + 8]
@@ -1019,11 +1027,12 @@ def test_flat_pair_kernel_generic_bounce(api, oracle, gpu_ready, scene_dir):
     for case, pair in (("mixed32_mis", True), ("metal32_mis", True), ("textured32_mis", False)):
         g = np.load(os.path.join(GOLDEN, case + ".npz"))
         hs = api.HostScene(golden_case_scene(g))
-        for opts in ({}, {"flat2": 0}, {"slice_iters": 8, "sched_mask": 3}):
+        for opts in ({}, {"flat2": 0}, {"slice_iters": 8, "sched_mask": 3}, {"lean": 0}):
             sc = api.Scene(hs, options=opts)
             col, _ = sc.render(hs.camera(), int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"]))
             fl = sc.flags()
             assert fl["flat"] and not fl["simple"] and fl["flat_pair"] == (pair and opts.get("flat2", 1) == 1), (case, opts, fl)
+            assert fl["lean"] == (fl["flat_pair"] and opts.get("lean", 1) == 1), (case, opts, fl)        # mirror / glass / metals: no leaf arm, no texture
             assert_bits_equal(col, g["colors"], "%s %s" % (case, opts))
     cfg = scenes.cornell(os.path.join(scene_dir, "pgmix"), 48, 32, 6, 12, tall_material=19, short_material=18, nested=True, doubled=4, name="pgmix")["config"]
     gs, hs, osc = _scene_pair(api, oracle, cfg)

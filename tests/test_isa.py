@@ -112,14 +112,21 @@ def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
         logic step peaks at ~125 live registers (no spill at a cap of 128, 31 spill sites at 96, 86 at 80, 159 at 64), the
         price of eight waves per SIMD that measures 2 % FASTER than six with 86 (profiles/r03_ab_hbm_simple_shapes_*.log)."""
     md = _metadata(isa)
-    flat2 = md["_ZN2pt16megakernel_flat2ILi0ELb1EEEvNS_7KParamsE"]
+    flat2 = md["_ZN2pt16megakernel_flat2ILi0ELb1ELb0EEEvNS_7KParamsE"]
     assert flat2["vgpr_count"] <= 128 and flat2["private_segment_fixed_size"] == 0 and flat2["vgpr_spill_count"] == 0, flat2
-    share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1EEEvNS_7KParamsE"]        # megakernel<0, false, false, false, true, false, true>: 4-wave REFILL SIMPLE
+    share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1ELb0EEEvNS_7KParamsE"]    # megakernel<0, false, false, false, true, false, true, 1, false>: 4-wave REFILL SIMPLE
     assert share["vgpr_count"] <= 128 and share["private_segment_fixed_size"] == 0 and share["vgpr_spill_count"] == 0, share
     hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
     assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 268, hbm
-    gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0EEEvNS_7KParamsE"]                    # generic bounce, REFILL, 6 waves per SIMD
+    gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb0EEEvNS_7KParamsE"]                # generic bounce (all arms), REFILL, 6 waves per SIMD
     assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 380, gen
+    # the LEAN generic bounce (no leaf arms, no texture fetches: scenes of glass, mirrors, metals) against the all-arms one
+    lean = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb1EEEvNS_7KParamsE"]
+    assert lean["vgpr_count"] == 80 and lean["private_segment_fixed_size"] <= 300, lean
+    lean4 = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb0ELi1ELb1EEEvNS_7KParamsE"]
+    assert lean4["private_segment_fixed_size"] <= 56, lean4
+    pair = md["_ZN2pt16megakernel_flat2ILi0ELb0ELb1EEEvNS_7KParamsE"]
+    assert pair["vgpr_count"] <= 128 and pair["private_segment_fixed_size"] <= 16, pair
 
 
 def _hot_loops(body):
@@ -148,8 +155,8 @@ def test_traversal_loops_of_the_kernels_for_scenes_in_hbm_hold_no_spill_code(isa
     live SGPR pairs made the compiler spill SGPRs INSIDE the loops (8 v_readlane / v_writelane per trip: -3 % on both scenes,
     profiles/r03_ab_state_shrink.log) — state that crosses the loops lives in VGPR bits. No spill code of either kind in there."""
     fns = _functions(isa)
-    for name in ("_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE", "_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0EEEvNS_7KParamsE",
-                 "_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1EEEvNS_7KParamsE"):
+    for name in ("_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE", "_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb0EEEvNS_7KParamsE",
+                 "_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb1EEEvNS_7KParamsE", "_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1ELb0EEEvNS_7KParamsE"):
         loops = _hot_loops(fns[name])
         assert len(loops) >= 2, (name, loops)
         assert all(ls == 0 and sc == 0 for (_, _, ls, sc) in loops), (name, loops)
