@@ -1,7 +1,9 @@
 """tools/roofline.py: the arithmetic behind bench.py's `roofline` block, and the committed evidence it is re-derived from.
 
-No GPU: the committed bench line of the round (profiles/r02_v16_bench.json) must follow from the committed counter sets
-(profiles/roofline_inputs.json) — every fraction at most 1, recomputable to the last digit."""
+No GPU: the committed bench line of the round (the newest profiles/rNN_v*_bench.json) must follow from the committed counter
+sets (profiles/roofline_inputs.json) — every fraction at most 1, recomputable to the last digit — and those counter sets must
+have been measured on the very kernels the built library holds (code_sha256): editing a kernel without re-running
+tools/profile_round.sh + tools/collect_round.py turns this file red."""
 import glob
 import json
 import os
@@ -12,9 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import roofline as RF  # noqa: E402
 
 
+def _bench_files():
+    def key(p):
+        r, v = os.path.basename(p).split("_")[:2]
+        return (int(r[1:]), int(v[1:]))
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_v*_bench.json")), key=key)
+
+
 def _latest_bench():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_v*_bench.json")), key=lambda p: int(os.path.basename(p).split("_")[1][1:]))
-    line = [ln for ln in open(files[-1]).read().splitlines() if ln.startswith("{")][-1]
+    line = [ln for ln in open(_bench_files()[-1]).read().splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
 
 
@@ -35,14 +43,49 @@ def test_valu_and_l1_rooflines_are_fractions():
 
 def test_committed_bench_line_follows_from_committed_inputs(capsys):
     b = _latest_bench()
+    assert os.path.basename(_bench_files()[-1]).startswith("r03_")
     assert RF.check(b)
     rows = [b] + b["secondary"]
-    assert all(0.0 < r["roofline"]["frac"] <= 1.0 for r in rows)
+    megak = [r for r in rows if r["config"]["variant"] == "megakernel"]
+    assert len(megak) == 5 and all(0.0 < r["roofline"]["frac"] <= 1.0 and not r["roofline"].get("stale_profile") for r in megak)
     assert b["metric"] == "Mray/s" and b["config"]["workload"] == "cornell_1920x1080_1024spp_depth8_mis" and b["frame_equals_counted_frame"]
-    assert b["roofline"]["kernel_ms"] <= b["ms_per_step"]
+    assert b["roofline"]["kernel_ms"] <= b["ms_per_step"] and b["roofline"]["bound"] == "valu"
+    names = [s["config"]["workload"].split(" ")[0] for s in b["secondary"]]
+    assert names == ["blob82k_1920x1080_1024spp_depth8_mis", "atrium262k_1920x1080_4096spp_depth16_mis", "cornell_mixed_1920x1080_1024spp_depth8_mis",
+                     "blob82k_glass_1920x1080_1024spp_depth8_mis", "atrium262k_1920x1080_4096spp_depth16_mis"]
     for s in b["secondary"]:
-        assert s["roofline"]["bound"] == "l1_lines" and 0.0 < s["roofline"]["ta_busy_frac"] <= 1.0
+        rf = s["roofline"]
+        if rf["bound"] == "l1_lines" and s["config"]["variant"] == "megakernel":
+            assert list(rf)[0] == "ta_busy_frac" and 0.0 < rf["ta_busy_frac"] <= 1.0 and "micro-benchmark" in rf["peak_source"]
+    # the general bounce (material dispatch, medium stack, dielectric / GGX / mirror arms) is in the driver's line, through its LEAN kernels
+    assert b["secondary"][2]["roofline"]["kernel"] == "pt::megakernel_flat2<0, false, true>" and b["secondary"][2]["config"]["kernel_flags"]["lean"]
+    assert b["secondary"][3]["roofline"]["kernel"] == "pt::megakernel_hbm<0, false, false, true, false, true>"
+    assert b["secondary"][4]["config"]["variant"] == "wavefront"                      # BASELINE configs[4]: the divergence A/B
+    assert set(b["projected_scaling"]) >= {"2", "4", "8"} and 1.0 < b["projected_scaling"]["8"] <= 8.0
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
+
+
+def test_committed_counters_were_measured_on_the_built_kernels(api):
+    """profiles/roofline_inputs.json carries the hash of each profiled kernel's machine code; the newest entry of every
+    (workload, spp, kernel) the bench line uses must be the code libptamd.so holds NOW — otherwise bench.py would report
+    `frac: null, stale_profile: true` on the driver's box (and this test says so first)."""
+    hashes = RF.kernel_code_hashes(api.LIB_PATH)
+    assert len(hashes) >= 30 and all(len(v) == 64 for v in hashes.values())
+    b = _latest_bench()
+    inputs = RF.load_inputs()
+    checked = 0
+    for row in [b] + b["secondary"]:
+        rf = row["roofline"]
+        if row["config"]["variant"] != "megakernel":
+            continue
+        e = RF.find_entry(inputs, row["config"]["workload"].split(" ")[0], row["config"]["spp"], rf["kernel"])
+        assert e is not None, rf["kernel"]
+        assert RF.profile_is_current(e, hashes), "%s was edited after its PMC pass (%s): re-run tools/profile_round.sh + tools/collect_round.py" % (rf["kernel"], e.get("source"))
+        assert rf["code_sha256"] == e["code_sha256"]
+        checked += 1
+    assert checked == 5
+    stale = dict(e, code_sha256="0" * 64)
+    assert not RF.profile_is_current(stale, hashes) and not RF.profile_is_current(None, hashes)
 
 
 def test_every_committed_build_of_the_round_rendered_the_same_full_frames():
@@ -50,9 +93,9 @@ def test_every_committed_build_of_the_round_rendered_the_same_full_frames():
     three workloads are the same bits in every build whose bench line is committed — kernels, layouts and options changed, the
     image did not."""
     seen = {}
-    for f in glob.glob(os.path.join(ROOT, "profiles", "r02_v*_bench.json")):
+    for f in _bench_files():
         b = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
         for row in [b] + b.get("secondary", []):
             if row.get("frame_sha"):
                 seen.setdefault(row["config"]["workload"], set()).add(row["frame_sha"])
-    assert len(seen) == 3 and all(len(v) == 1 for v in seen.values()), seen
+    assert len(seen) == 5 and all(len(v) == 1 for v in seen.values()), seen       # rounds 2 and 3: kernels, layouts and node numbering changed, the frames did not

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The measurements one round commits under profiles/ (run on the GPU box): tools/profile_round.sh TAG
+# The measurements one round commits under profiles/ (run on the GPU box): tools/profile_round.sh TAG [fullspp]
 #   1. PMC passes (tools/pmc_passes.sh: counters in their own runs, --kernel-trace only) for the headline workload and the
 #      two secondary workloads -> entries of profiles/roofline_inputs.json (tools/roofline.py collect)
 #   2. rocprofv3 --kernel-trace --stats of bench.py -> per-kernel average durations
@@ -26,10 +26,16 @@ PY
   echo "pmc $3 done (kernel under the profiler $ms ms)"
 }
 run_pmc cornell_1920x1080_1024spp_depth8_mis 1024 cornell
-run_pmc atrium262k_1920x1080_4096spp_depth16_mis 32 atrium_spp32 "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"      # scenes in HBM: how busy the texture addresser is
-run_pmc blob82k_1920x1080_1024spp_depth8_mis 1024 blob "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"
+run_pmc atrium262k_1920x1080_4096spp_depth16_mis 32 atrium_spp32 "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"      # scenes in HBM: how busy the texture addresser is, and the scratch share of its instructions
+run_pmc blob82k_1920x1080_1024spp_depth8_mis 1024 blob "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+run_pmc cornell_mixed_1920x1080_1024spp_depth8_mis 1024 cornell_mixed                                       # the general bounce, LDS-resident (VALU roofline)
+run_pmc blob82k_glass_1920x1080_1024spp_depth8_mis 128 blob_glass_spp128 "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"  # the general bounce, scene in HBM
 cp profiles/roofline_inputs.json $out/roofline_inputs.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/stats.log 2>&1 )
 python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err
 python tools/roofline.py check $out/bench.json
 tail -c 400 $out/bench.json
+if [ "$2" = "fullspp" ]; then      # BASELINE configs[3] at its own 4096 spp on one GPU (~4 min: a counted and a timed frame)
+  python bench.py --workload atrium262k_1920x1080_4096spp_depth16_mis --steps 1 --warmup 1 --no-cpu-baseline > $out/bench_atrium262k_fullspp.json 2> $out/bench_atrium262k_fullspp.err
+  tail -c 300 $out/bench_atrium262k_fullspp.json
+fi
