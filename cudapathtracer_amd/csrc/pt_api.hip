@@ -111,8 +111,13 @@ static int queue_error(pt_scene* s);
 static int scene_onchip_wg(const pt_scene* s) {
     if (!s->onchipOk || s->nTrisPacked <= 0 || s->ds.stackSpill != 0) return 0;
     const size_t geom = (size_t)s->nInternal * 64 + (size_t)s->nTrisPacked * 48, rec = attr_cache_bytes(s->nTrisPacked, s->nMats, s->nLightsPacked);
+    // ... and 16 / wg such workgroups must fit a CU's 160 KB with the largest per-wave area any LDS-resident kernel uses (the pair
+    // pass scratch, 24 x 256 B, plus the medium stack of the non-SIMPLE kernels): a Cornell box of glass, water and gold at four
+    // waves per workgroup was 1 KB over — three workgroups per CU instead of four, 19 % of the frame (round 3)
+    const size_t perWave = (size_t)kStackFlat2Rows * 256 + (s->simpleOk && s->simpleWanted ? 0 : (size_t)kMediumMax * 64);
     for (int wg = 4; wg <= 16; wg *= 2)
-        if (geom <= (size_t)kCacheBytes * (wg / 4) && (kAttrCacheBytes == 0 || rec <= (size_t)kAttrCacheBytes * (wg / 4))) return wg;
+        if (geom <= (size_t)kCacheBytes * (wg / 4) && (kAttrCacheBytes == 0 || rec <= (size_t)kAttrCacheBytes * (wg / 4)) &&
+            geom + rec + (size_t)wg * perWave <= (size_t)160 * 1024 * wg / 16) return wg;
     return 0;
 }
 static bool scene_onchip(const pt_scene* s) { return scene_onchip_wg(s) > 0; }
@@ -391,6 +396,47 @@ static int repack(pt_scene* s, const pt_scene_desc* d, int deviceLeaf = -1, pt_b
         nInternal = out5[0]; stackNeed = out5[1]; rootRef = out5[2];
         if (out5[3]) s->armless = true;
         if (stackNeed > 128) return fail(-1, "pt_scene_create_from_mesh: BVH depth %d exceeds the reference's nodeStack[128] (integratorUtilities.cuh:89)", stackNeed);
+#if PT_NODE_ORDER_AREA
+        // the same numbering as the host re-pack gives scenes in HBM (above): descending surface area of a node's own box — here
+        // read from its parent's record, the same floats — so that the LDS copy of PNodes [0, K) holds the most-visited ones
+        if (nInternal > 128 && rootRef == 0) {
+            std::vector<PNode> pn((size_t)nInternal);
+            HIP_OK(hipMemcpy(pn.data(), s->nodes.p, (size_t)nInternal * sizeof(PNode), hipMemcpyDeviceToHost));
+            std::vector<float> area((size_t)nInternal, 0.0f);
+            std::vector<int> bfs; bfs.reserve((size_t)nInternal); bfs.push_back(0);
+            std::vector<uint8_t> seen((size_t)nInternal, 0); seen[0] = 1;
+            bool tree = true;
+            for (size_t q = 0; q < bfs.size() && tree; q++) {
+                const PNode& p = pn[bfs[q]];
+                const int32_t ref[2] = {p.left, p.right};
+                for (int k = 0; k < 2; k++) {
+                    if (ref[k] < 0) continue;
+                    if (ref[k] >= nInternal || seen[ref[k]]) { tree = false; break; }
+                    seen[ref[k]] = 1;
+                    const float* mn = k == 0 ? p.lmin : p.rmin; const float* mx = k == 0 ? p.lmax : p.rmax;
+                    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+                    const float a = dx * dy + dy * dz + dz * dx;
+                    area[ref[k]] = std::isfinite(a) ? a : 0.0f;
+                    bfs.push_back(ref[k]);
+                }
+            }
+            if (tree && (int)bfs.size() == nInternal) {
+                // bfs[k]: k-th node in breadth-first order; sort those positions by area (stable: ties keep breadth-first order)
+                std::vector<int> order(bfs);
+                std::stable_sort(order.begin() + 1, order.end(), [&](int a, int b) { return area[a] > area[b]; });
+                std::vector<int> rank((size_t)nInternal);
+                for (int k = 0; k < nInternal; k++) rank[order[k]] = k;
+                std::vector<PNode> out((size_t)nInternal);
+                for (int i = 0; i < nInternal; i++) {
+                    PNode p = pn[i];
+                    if (p.left >= 0) p.left = rank[p.left];
+                    if (p.right >= 0) p.right = rank[p.right];
+                    out[rank[i]] = p;
+                }
+                HIP_OK(hipMemcpy(s->nodes.p, out.data(), (size_t)nInternal * sizeof(PNode), hipMemcpyHostToDevice));
+            }
+        }
+#endif
     }
     if (int r = upload(s->lights, lights.data(), lights.size() * sizeof(PLight))) return r;
     if (int r = upload(s->mats, mats.data(), mats.size() * sizeof(PMat))) return r;

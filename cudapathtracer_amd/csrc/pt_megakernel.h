@@ -504,8 +504,8 @@ megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLd
 
 // FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): scenes of at most 64 nodes / triangles none of which is a MAT_LEAF
 // (any hit occludes a shadow ray) and all of whose materials have a dispatch arm (the DEFER logic step is exact), MIS
-// integrator; with the SIMPLE bounce where the scene allows. The wave's "stack" area is the 25 x 64-word scratch of the tests.
-constexpr int kStackFlat2 = 25;
+// integrator; with the SIMPLE bounce where the scene allows. The wave's "stack" area is the 24 x 64-word scratch of the tests.
+constexpr int kStackFlat2 = kStackFlat2Rows;
 template <int INTEG, bool SIMPLE, bool LEAN = false>
 __global__ void __launch_bounds__(1024)
 #if PT_MIN_WAVES > 0

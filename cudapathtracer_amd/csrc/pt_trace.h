@@ -669,17 +669,20 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
 // that continues the path share ONE lockstep node walk (node fetch, child refs, loop control paid once for both), and
 // their triangle tests are dealt out over the wave together. A shadow ray needs no order at all when no triangle of the
 // scene is a MAT_LEAF (NOLEAF scenes: any hit below max_t occludes), the extension ray is resolved as in
-// trace_closest_flat. At most 64 internal nodes / triangles. Scratch: 25 x 64 words of the wave's stack area:
+// trace_closest_flat. At most 64 internal nodes / triangles. Scratch: 24 x 64 words of the wave's stack area:
 //   entry v = lane (extension ray) or 64 + lane (shadow ray): o, d, max_t, triangle mask (9 fields x 128), exclusive
 //   prefix (128), the two u64 keys of the extension rays (2 x 128 words), the occlusion flags (64).
 template <int N>
 PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>& st, bool hasShadow, V3 so, V3 sd, float smaxt,
                             bool hasExt, V3 eo, V3 ed, V3& thr, Hit& hit, Ctr& c, int nInternal, const PLeaf* __restrict__ leaves = nullptr, int nLeaves = 0) {
-    static_assert(N >= 25, "the scratch layout needs 25 x 64 words of the wave's stack area");
+    static_assert(N >= 24, "the scratch layout needs 24 x 64 words of the wave's stack area");
     typedef __attribute__((address_space(3))) unsigned long long lds_u64;
     const int lane = (int)(threadIdx.x & 63u);
     lds_i32* Wd = st.lds - lane;
-    constexpr int kPre = 9 * 128, kKeys = kPre + 128, kOcc = kKeys + 256;
+    // (the occlusion flags of the 64 shadow rays reuse the first half of the prefix field: the prefixes are only read by the owner
+    // search, which every lane of the wave has finished before the first test can set a flag — 24 x 256 B per wave instead of 25,
+    // which is what lets a fifth 4-wave workgroup fit a CU's 160 KB next to its copy of the Cornell scene)
+    constexpr int kPre = 9 * 128, kKeys = kPre + 128, kOcc = kPre;
     const V3 invE = inv3(ed), invS = inv3(sd);
     // 1. one lockstep node walk for both rays
     uint64_t tmE = 0ull, tmS = 0ull;
@@ -740,7 +743,6 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     lds_u64* kLo = (lds_u64*)(Wd + kKeys);
     lds_u64* kHi = (lds_u64*)(Wd + kKeys + 128);
     kLo[lane] = ~0ull; kHi[lane] = ~0ull;
-    Wd[kOcc + lane] = 0;
     wave_lds_sync();
     const int per = (total + 63) >> 6;
     int p = lane * per;
@@ -761,6 +763,9 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
         fetch(l);
         rem &= ~((1ull << select64(rem, p - Wd[kPre + l])) - 1ull);
     }
+    wave_lds_sync();                                              // every lane has read its prefixes ...
+    Wd[kOcc + lane] = 0;                                          // ... their first 64 words now hold the shadow rays' "occluded" flags
+    wave_lds_sync();
     for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
         if (p < pEnd) {
             while (rem == 0ull) { l++; fetch(l); }                // next ray that has tests (there is one: p < total)
