@@ -214,8 +214,17 @@ PT_DEV int lanes_here() { return __builtin_popcountll(__builtin_amdgcn_ballot_w6
 // grazing incidence), so this mode is NOT the reference's result: 13 of 2 M pixels differ after 4.6e9 rays on the
 // 263 k-triangle scene. The default instantiations do not contain the test.
 template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
+PT_DEV int32_t descend_node(const NodeData& n, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c, float cullT = 0.0f);
+
+template <bool COUNT, int N, bool ONCHIP = false, bool CULL = false>
 PT_DEV int32_t descend(const DeviceScene& S, const SceneCache& C, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c, float cullT = 0.0f) {
-    NodeData n = load_node<ONCHIP>(S, C, cur);
+    const NodeData n = load_node<ONCHIP>(S, C, cur);
+    return descend_node<COUNT, N, ONCHIP, CULL>(n, cur, o, inv, st, c, cullT);
+}
+
+// ... the step itself, on a record that is already in registers.
+template <bool COUNT, int N, bool ONCHIP, bool CULL>
+PT_DEV int32_t descend_node(const NodeData& n, int32_t cur, V3 o, V3 inv, Stack<N>& st, Ctr& c, float cullT) {
     if (COUNT) { c.pops++; c.boxes += 2; if (!ONCHIP && (uint32_t)cur >= c.gnodeFrom) c.gnodes++; }
     float tL, tR;
     bool hL = slab(n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, o, inv, tL);
