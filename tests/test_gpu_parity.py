@@ -801,6 +801,27 @@ def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_r
     assert not outside.any()                                       # nothing outside the tile was touched
 
 
+@pytest.mark.parametrize("config", ["C2_cornell", "C3_blob82k", "C4_atrium263k"])
+def test_full_1080p_frame_vs_oracle(api, oracle, gpu_ready, scene_dir, config):
+    """Every pixel of the 1920x1080 frame of each BASELINE scene — all 32 400 tiles through the production kernels in ONE launch,
+    tile queue, time slices, scheduling and all — against a live oracle render of the whole frame at a low sample count (the
+    per-pixel streams at full length are the deep-stream tests' subject): 2 073 600 pixels bit for bit, and the frame's hash is
+    what bench.py would print."""
+    from cudapathtracer_amd import scenes
+    gen, kw = {"C2_cornell": ("cornell", dict(spp=4, max_depth=8)), "C3_blob82k": ("blob_in_box", dict(spp=2, max_depth=8)),
+               "C4_atrium263k": ("atrium", dict(spp=1, max_depth=16))}[config]
+    w, h = 1920, 1080
+    s = getattr(scenes, gen)(os.path.join(scene_dir, "full_" + config), width=w, height=h, name="full_" + gen, **kw)
+    hs = api.HostScene(s["config"])
+    sc = api.Scene(hs)
+    got, _ = sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"])
+    fl = sc.flags()
+    assert fl["simple"] and fl["persistent"] and (fl["flat_pair"] if gen == "cornell" else fl["hbm_kernel"] and fl["refill"]), fl
+    want, _, secs = oracle.OracleScene(s["config"]).render(threads=16)
+    assert want.shape == (h, w, 4) and float(np.nan_to_num(want[..., :3], nan=0.0, posinf=0.0, neginf=0.0).sum()) > 0.0     # (NaN pixels the reference itself produces are part of the frame, DESIGN.md §4)
+    assert_bits_equal(got, want, "%s, full 1080p frame at %d spp (oracle: %.1f s)" % (config, kw["spp"], secs))
+
+
 def test_fuzz_scene_depth16(api, oracle, gpu_ready, scene_dir):
     """A random scene over the whole material table at the C4 depth: Russian roulette only after 16 bounces."""
     from cudapathtracer_amd import scenes
