@@ -801,7 +801,7 @@ def test_deep_stream_one_tile_at_the_configs_own_sample_count(api, oracle, gpu_r
     assert not outside.any()                                       # nothing outside the tile was touched
 
 
-@pytest.mark.parametrize("config", ["C2_cornell", "C3_blob82k", "C4_atrium263k"])
+@pytest.mark.parametrize("config", ["C2_cornell", "C3_blob82k", "C4_atrium263k", "mixed_cornell", "glass_blob82k", "C2_cornell_naive", "C3_blob82k_naive"])
 def test_full_1080p_frame_vs_oracle(api, oracle, gpu_ready, scene_dir, config):
     """Every pixel of the 1920x1080 frame of each BASELINE scene — all 32 400 tiles through the production kernels in ONE launch,
     tile queue, time slices, scheduling and all — against a live oracle render of the whole frame at a low sample count (the
@@ -809,15 +809,22 @@ def test_full_1080p_frame_vs_oracle(api, oracle, gpu_ready, scene_dir, config):
     what bench.py would print."""
     from cudapathtracer_amd import scenes
     gen, kw = {"C2_cornell": ("cornell", dict(spp=4, max_depth=8)), "C3_blob82k": ("blob_in_box", dict(spp=2, max_depth=8)),
-               "C4_atrium263k": ("atrium", dict(spp=1, max_depth=16))}[config]
+               "C4_atrium263k": ("atrium", dict(spp=1, max_depth=16)),
+               # the general bounce (bench.py's secondary workloads) and Li_naive_unidirectional (deviceCode.cu:158-205)
+               "mixed_cornell": ("cornell", dict(spp=4, max_depth=8, tall_material=19, short_material=5, nested=True, extra_boxes=1, extra_materials=[4])),
+               "glass_blob82k": ("blob_in_box", dict(spp=2, max_depth=8, material=5)),
+               "C2_cornell_naive": ("cornell", dict(spp=4, max_depth=8)), "C3_blob82k_naive": ("blob_in_box", dict(spp=2, max_depth=8))}[config]
+    integ = 2 if config.endswith("_naive") else 0
+    generic = config in ("mixed_cornell", "glass_blob82k")
     w, h = 1920, 1080
     s = getattr(scenes, gen)(os.path.join(scene_dir, "full_" + config), width=w, height=h, name="full_" + gen, **kw)
     hs = api.HostScene(s["config"])
     sc = api.Scene(hs)
-    got, _ = sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"])
+    got, _ = sc.render(hs.camera(), w, h, kw["spp"], kw["max_depth"], integrator=integ)
     fl = sc.flags()
-    assert fl["simple"] and fl["persistent"] and (fl["flat_pair"] if gen == "cornell" else fl["hbm_kernel"] and fl["refill"]), fl
-    want, _, secs = oracle.OracleScene(s["config"]).render(threads=16)
+    assert fl["simple"] == (not generic) and fl["lean"] == generic and fl["persistent"], fl
+    assert (fl["flat"] and fl["flat_pair"] == (integ == 0)) if gen == "cornell" else (fl["hbm_kernel"] and fl["refill"]), fl
+    want, _, secs = oracle.OracleScene(s["config"]).render(threads=16, integrator=integ)
     assert want.shape == (h, w, 4) and float(np.nan_to_num(want[..., :3], nan=0.0, posinf=0.0, neginf=0.0).sum()) > 0.0     # (NaN pixels the reference itself produces are part of the frame, DESIGN.md §4)
     assert_bits_equal(got, want, "%s, full 1080p frame at %d spp (oracle: %.1f s)" % (config, kw["spp"], secs))
 
