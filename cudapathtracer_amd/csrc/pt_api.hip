@@ -698,6 +698,34 @@ static int ensure_wide(pt_scene* s) {
         need[w] = (wn[w].pad[0] - 1) + below;         // the other slots wait on the stack while one is descended into
         worst = std::max(worst, need[w]);
     }
+#if PT_NODE_ORDER_AREA
+    // as for the binary nodes: the LDS copy holds wide nodes [0, K) — number them by the area of their own box (the slot box in
+    // their parent), root first, so that K most-visited ones are cached
+    if (wn.size() > 128) {
+        const int nW = (int)wn.size();
+        std::vector<float> area((size_t)nW, 0.0f);
+        for (int w = 0; w < nW; w++)
+            for (int i = 0; i < 4; i++) {
+                const int32_t c = wn[w].ref[i];
+                if (c < 0 || c >= nW) continue;
+                const float dx = wn[w].mxx[i] - wn[w].mnx[i], dy = wn[w].mxy[i] - wn[w].mny[i], dz = wn[w].mxz[i] - wn[w].mnz[i];
+                const float a = dx * dy + dy * dz + dz * dx;
+                area[c] = std::isfinite(a) ? a : 0.0f;
+            }
+        std::vector<int> order((size_t)nW);
+        for (int w = 0; w < nW; w++) order[w] = w;
+        std::stable_sort(order.begin() + 1, order.end(), [&](int a, int b) { return area[a] > area[b]; });
+        std::vector<int> rank((size_t)nW);
+        for (int k = 0; k < nW; k++) rank[order[k]] = k;
+        std::vector<WNode> out((size_t)nW);
+        for (int w = 0; w < nW; w++) {
+            WNode x = wn[w];
+            for (int i = 0; i < 4; i++) if (x.ref[i] >= 0 && x.ref[i] < nW) x.ref[i] = rank[x.ref[i]];
+            out[rank[w]] = x;
+        }
+        wn.swap(out);
+    }
+#endif
     if (int r = upload(s->wnodes, wn.data(), wn.size() * sizeof(WNode))) return r;
     s->nWide = (int)wn.size(); s->wideStackNeed = worst;
     return 0;

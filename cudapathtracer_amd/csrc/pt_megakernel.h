@@ -348,7 +348,7 @@ PT_DEV void megakernel_body(const KParams& P) {
                         if (hasShadow) thr = trace_shadow_plain<false, STACKN, false, false, true>(S, none, ps.so, ps.sd, ps.smaxt, st, c);
                         h.tri = -1; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.material = 0;
                         if (hasExt) trace_closest_plain<false, STACKN, false, false>(S, none, ps.o, ps.d, 999999.0f, st, h, c);
-                        rs.flags = 0u;
+                        rs.flags = (hasShadow && thr.x == 0.0f) ? kRayOccluded : 0u;      // (a NOLEAF scene: the throughput is 0 or 1; the next logic step reads the bit)
                     } else
 #endif
                     ray_start<COUNT, STACKN>(S, st, rs, hasShadow, ps.so, ps.sd, ps.smaxt, hasExt, ps.o, ps.d, thr, h, c);
@@ -379,12 +379,12 @@ PT_DEV void megakernel_body(const KParams& P) {
 #if !defined(PT_EXPERIMENTAL)
             trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
-            if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
-            else trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+            else trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 1
-            trace_resume_spec<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
+            trace_resume_spec<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
 #else
-            trace_resume<COUNT, STACKN, ONCHIP, SIMPLE>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #endif
             PT_STAMP(1);
             continue;

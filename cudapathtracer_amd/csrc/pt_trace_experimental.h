@@ -100,6 +100,7 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
     float max_t = r.max_t, min_t = r.min_t;
     int32_t cur = r.cur, pend = r.pend;
     bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    uint32_t occlBits = r.flags & kRayOccluded;        // NOLEAF scenes: the caller reads the shadow ray's result from this bit (pt_trace.h: RayState)
     while (true) {
         const int active = lanes_here();
         if (active <= minBusy) break;
@@ -136,7 +137,7 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
                 if (isShadow) {
                     if (ok && (t < max_t)) {
                         uint32_t flags = f2u(q.e.w);
-                        if (NOLEAF || !(flags & 1u)) { thr = v3(0.0f); occluded = true; break; }
+                        if (NOLEAF || !(flags & 1u)) { thr = v3(0.0f); if (NOLEAF) occlBits = kRayOccluded; occluded = true; break; }
                         // MAT_LEAF (integratorUtilities.cuh:218-239)
                         const PMat& m = S.mats[f2i(q.e.z)];
                         const PAttr& at = S.attrs[idx & 0x7fffffffu];
@@ -178,7 +179,7 @@ PT_DEV void trace_resume_spec(const DeviceScene& S, const SceneCache& C, Stack<N
         }
     }
     r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur; r.pend = pend;
-    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | occlBits;
     if (COUNT) { if (!busy && !isShadow && h.tri >= 0) c.hits++; }
 }
 
@@ -230,6 +231,7 @@ PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Comp
     float max_t = r.max_t, min_t = r.min_t;
     int32_t cur = r.cur;
     bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, busy = true;
+    uint32_t occlBits = r.flags & kRayOccluded;        // NOLEAF scenes: the caller reads the shadow ray's result from this bit (pt_trace.h: RayState)
     bool exact = !inv_is_regular(inv);
     const int nLdsQ = C.nNodes << 1;                               // the LDS scene cache holds the first nLdsQ compact nodes (2 per 64 bytes)
     while (true) {
@@ -300,7 +302,7 @@ PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Comp
                 float t, u, v;
                 bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
                 if (isShadow) {
-                    if (ok && (t < max_t)) { thr = v3(0.0f); occluded = true; break; }       // NOLEAF scene: any hit ends the ray
+                    if (ok && (t < max_t)) { thr = v3(0.0f); occlBits = kRayOccluded; occluded = true; break; }       // NOLEAF scene: any hit ends the ray
                 } else if (ok && (t < max_t)) {
                     bool take = t < min_t;
                     if (!take && t == min_t && h.tri >= 0) take = !tie_keeps_first(S, K.mids, o, inv, bestTi, ti);
@@ -321,7 +323,7 @@ PT_DEV void trace_resume_q(const DeviceScene& S, const SceneCache& C, const Comp
         if (occluded) st.sp = 0;
     }
     r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur; r.pend = bestTi;
-    r.flags = (inLeaf ? kRayInLeaf : 0u) | (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u);
+    r.flags = (inLeaf ? kRayInLeaf : 0u) | (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | occlBits;
 }
 
 // ---- wide traversal (SIMPLE scenes in HBM) --------------------------------------------------------
@@ -347,6 +349,7 @@ PT_DEV void trace_resume_w4(const DeviceScene& S, const SceneCache& C, const WNo
     float max_t = r.max_t, min_t = r.min_t;
     int32_t cur = r.cur;
     bool isShadow = (r.flags & kRayShadow) != 0, extFollows = (r.flags & kRayExtFollows) != 0, tie = (r.flags & kRayTie) != 0, busy = true;
+    uint32_t occlBits = r.flags & kRayOccluded;
     const int nLdsW = C.nNodes >> 1;                               // the LDS scene cache holds the first nLdsW wide nodes (2 x 64 B each)
     while (true) {
         const int active = lanes_here();
@@ -394,7 +397,7 @@ PT_DEV void trace_resume_w4(const DeviceScene& S, const SceneCache& C, const WNo
             float t, u, v;
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (isShadow) {
-                if (ok && (t < max_t)) { thr = v3(0.0f); occluded = true; break; }       // NOLEAF scene: any hit ends the ray
+                if (ok && (t < max_t)) { thr = v3(0.0f); occlBits = kRayOccluded; occluded = true; break; }       // NOLEAF scene: any hit ends the ray
             } else if (ok && (t < max_t)) {
                 if (t < min_t) {
                     min_t = t; tie = false;
@@ -412,7 +415,7 @@ PT_DEV void trace_resume_w4(const DeviceScene& S, const SceneCache& C, const WNo
         if (occluded) st.sp = 0;
     }
     r.o = o; r.d = d; r.inv = inv; r.max_t = max_t; r.min_t = min_t; r.cur = cur;
-    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | (tie ? kRayTie : 0u);
+    r.flags = (busy ? kRayBusy : 0u) | (isShadow ? kRayShadow : 0u) | (extFollows ? kRayExtFollows : 0u) | (tie ? kRayTie : 0u) | occlBits;
 }
 
 }  // namespace pt
