@@ -115,6 +115,7 @@ def lib():
     L.pt_last_kernel_ms.restype = f32; L.pt_last_kernel_ms.argtypes = [vp]
     L.pt_scene_flags.argtypes = [vp]
     L.pt_last_tile_handovers.argtypes = [vp]
+    L.pt_queue_stalls.argtypes = [vp]
     L.pt_set_culling.argtypes = [vp, i32]
     L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
     L.pt_get_option.argtypes = [vp, C.c_char_p, vp]
@@ -454,6 +455,10 @@ class Scene:
         n = lib().pt_last_tile_handovers(self.h)
         _check(min(n, 0), "pt_last_tile_handovers")
         return n
+
+    def queue_stalls(self):
+        """pt_queue_stalls: launches whose queue waiters gave up although the frame was complete (not an error)."""
+        return int(lib().pt_queue_stalls(self.h))
 
     def last_kernel_ms(self):
         """Device time of the last launch; raises if that launch did not finish its frame (tile-queue timeout).

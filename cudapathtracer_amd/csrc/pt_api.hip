@@ -79,6 +79,8 @@ struct pt_scene {
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
     bool noLeafTris = false;                      // no triangle carries a MAT_LEAF material: a shadow ray is occluded by any hit (order-free)
+    int queueTimeoutMs = 30000;                   // "queue_timeout_ms": how long a wait on the tile queue may see no progress (tests use 0-1 to exercise the give-up path)
+    int queueStalls = 0;                          // launches whose waiters gave up (q[3] != 0) although every tile was finished: not an error, counted (pt_queue_stalls)
     bool leanOk = false, leanWanted = true;       // scene qualifies for the LEAN generic bounce (no MAT_LEAF triangle, no texture / transmission map on any triangle's material) / "lean" 0 turns it off (A/B)
     int lastLaunchLean = 0;
     bool simpleOk = false, simpleWanted = true;   // scene qualifies for the SIMPLE bounce (diffuse-only, pt_path.h) / "simple" 0 turns it off (A/B)
@@ -912,6 +914,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.hbm = hbm ? 1 : 0;
     P.queue = nullptr; P.queueMask = 0; P.left = nullptr; P.gridBlocks = 0;
     P.lptPrio = s->lptPrio; P.sliceIters = s->sliceIters; P.schedMask = s->schedMask; P.sliceAlways = s->sliceAlways ? 1 : 0;
+    P.queueTimeout = (unsigned long long)s->queueTimeoutMs * 100000ull;        // ms -> ticks of the 100 MHz steady counter (hipDeviceAttributeWallClockRate)
     if (s->persistent && !s->xcdBands) {
         int cap = 256;
         while (cap < t.count) cap <<= 1;
@@ -1080,9 +1083,16 @@ int pt_debug_stamps(pt_scene* s, unsigned long long* out8) {
 // unfinished frame. Read where the host waits for the kernel anyway.
 static int queue_error(pt_scene* s) {
     if (!s->queue.p || s->variant != 0 || !s->lastLaunchQueued) return 0;     // (an error word left by an earlier queued launch is not this launch's)
-    int q[4] = {0, 0, 0, 0};
+    int q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess) return fail(-2, "tile queue read-back failed");
-    if (q[3] != 0) return fail(-4, "megakernel tile queue timed out (code %d, %d tiles finished): the frame is incomplete", q[3], q[2]);
+    if (q[3] != 0) {
+        // A waiter saw no progress for the whole timeout and left. Waiters hold no tile: the frame is complete iff every tile has
+        // been finished (each wave counts its tile in q[2] after its last state store, and the kernel has ended). Only an
+        // unfinished tile — one yielded after the waiters had gone — is an error.
+        if (q[2] >= s->lastLaunchTiles) { s->queueStalls++; return 0; }
+        return fail(-4, "megakernel tile queue timed out (code %d): %d of %d tiles finished, %d pops and %d pushes claimed; the first waiter gave up at %d finished after %.1f M ticks "
+                        "of the device's steady counter without progress: the frame is incomplete", q[3], q[2], s->lastLaunchTiles, q[0], q[1], q[6], (double)q[7] * 1.048576);
+    }
     return 0;
 }
 
@@ -1095,6 +1105,9 @@ int pt_last_tile_handovers(pt_scene* s) {
     HIP_OK(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
     return std::max(0, q[1] - s->lastLaunchTiles);
 }
+
+// Launches of this scene whose queue waiters gave up (no progress for "queue_timeout_ms") although the frame was complete.
+int pt_queue_stalls(pt_scene* s) { return s ? s->queueStalls : 0; }
 
 int pt_set_culling(pt_scene* s, int on) {
     if (!s) return fail(-1, "null scene");
@@ -1112,7 +1125,7 @@ const OptionRef kOptions[] = {
     {"flat", 0, 2}, {"onchip", 0, 1}, {"waves_hbm", 0, 2}, {"refill", 0, 2}, {"refill_keep", 0, 15}, {"node_keep", 0, 15}, {"tri_keep", 0, 15},
     {"defer_shadow", 0, 1}, {"slice_iters", 0, 1 << 30}, {"slice_always", 0, 1}, {"sched_mask", 0, 1 << 20}, {"lpt_prio", 0, 2},
     {"persistent", 0, 1}, {"xcd_bands", 0, 1}, {"culling", 0, 1}, {"spec", 0, 2}, {"simple", 0, 1}, {"flat2", 0, 1}, {"leaf_boxes", 0, 1}, {"wide", 0, 1},
-    {"compact", 0, 1}, {"wf_wide_wg", 0, 2}, {"lean", 0, 1},
+    {"compact", 0, 1}, {"wf_wide_wg", 0, 2}, {"lean", 0, 1}, {"queue_timeout_ms", 0, 1 << 22},
 };
 int option_index(const char* name) {
     if (!name) return -1;
@@ -1157,6 +1170,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 20: s->compactWanted = v != 0; break;
         case 21: s->wfWideWg = v; break;
         case 22: s->leanWanted = v != 0; break;
+        case 23: s->queueTimeoutMs = v; break;
     }
     return 0;
 }
@@ -1187,6 +1201,7 @@ int pt_get_option(pt_scene* s, const char* name, int* out) {
         case 20: *out = s->compactWanted; break;
         case 21: *out = s->wfWideWg; break;
         case 22: *out = s->leanWanted; break;
+        case 23: *out = s->queueTimeoutMs; break;
         default: return fail(-1, "pt_get_option: unknown option '%s'", name ? name : "(null)");
     }
     return 0;

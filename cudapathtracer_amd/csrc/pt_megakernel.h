@@ -81,13 +81,16 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 // "state before the queue entry" is the wave waiting for its own stores: an explicit `s_waitcnt vmcnt(0)` between the
 // last state store and queue_push (see the end of megakernel_body; no fence emits it by itself).
 // Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
-// surface as an error code, never as a hung GPU.
+// surface as an error code, never as a hung GPU. The flag by itself is not an error (round 3): waiters that give up hold no
+// tile, and the frame is complete iff q[2] == tiles when the kernel has ended — which is what the host checks; a stall of
+// the device (seen once with four persistent kernels co-resident on one device inside a long-lived process) then costs
+// the waiters, not the frame. A tile yielded AFTER the waiters have left finds nobody to continue it: q[2] < tiles, an error.
 constexpr int kFreshBit = 1 << 30;
-constexpr unsigned long long kQueueTimeout = 3000000000ull;            // 30 s of the 100 MHz wall clock without any progress
+constexpr unsigned long long kQueueTimeout = 3000000000ull;            // default: 30 s of the 100 MHz wall clock without any progress (KParams::queueTimeout)
 #define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
-PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
+PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait, unsigned long long timeout) {
     int item = -1;
     if (lane == 0) {
         const unsigned pos = atomicAdd((unsigned*)&q[0], 1u);
@@ -110,21 +113,26 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
                 const int progress = done + PT_QLOAD(&q[1]);
                 const unsigned long long now = wall_clock64();
                 if (progress != seen) { seen = progress; t0 = now; }
-                else if (now - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 1); break; }
+                else if (now - t0 > timeout) {
+                    // what the waiter saw, for the host's error message: tiles finished and the wait in 2^20-tick units (q[6], q[7] are spare)
+                    PT_QSTORE(&q[6], done); PT_QSTORE(&q[7], (int)((now - t0) >> 20));
+                    PT_QSTORE(&q[3], 1);
+                    break;
+                }
             }
             __builtin_amdgcn_s_sleep(64);
         }
     }
     return __builtin_amdgcn_readfirstlane(item);
 }
-PT_DEV void queue_push(int* q, int mask, int item, int lane) {
+PT_DEV void queue_push(int* q, int mask, int item, int lane, unsigned long long timeout) {
     if (lane == 0) {
         const unsigned pos = atomicAdd((unsigned*)&q[1], 1u);
         unsigned long long* slot = queue_slot(q, mask, pos);
         const unsigned long long t0 = wall_clock64();
         while ((unsigned)PT_QLOAD(slot) != pos) {
             if (PT_QLOAD(&q[3]) != 0) return;
-            if (wall_clock64() - t0 > kQueueTimeout) { PT_QSTORE(&q[3], 2); return; }
+            if (wall_clock64() - t0 > timeout) { PT_QSTORE(&q[3], 2); return; }
             __builtin_amdgcn_s_sleep(4);
         }
         PT_QSTORE(slot, ((unsigned long long)(unsigned)item << 32) | (unsigned long long)(pos + 1u));
@@ -191,7 +199,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     int lt;
     bool fresh = true;
     if (P.queue) {
-        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0);
+        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0, P.queueTimeout);
         if (item < 0) break;
         fresh = (item & kFreshBit) != 0;
         lt = item & ~kFreshBit;
@@ -461,7 +469,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             // "memory" clobber keeps the compiler from moving the queue accesses above it; tests/test_isa.py checks the
             // instruction order in every non-counting instantiation.
             asm volatile("; PT_YIELD_STATE_STORED\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            queue_push(P.queue, P.queueMask, lt, lane);
+            queue_push(P.queue, P.queueMask, lt, lane, P.queueTimeout);
         } else if (lane == 0) atomicAdd(&P.queue[2], 1);
     }
     if (COUNT) {

@@ -179,6 +179,11 @@ float pt_last_kernel_ms(pt_scene* scene);
 /* Tile hand-overs of the last megakernel launch (call after it has completed): how many times a wave yielded its tile at
  * the end of a time slice for another wave to continue (0 without time slices). For tests and scheduling measurements. */
 int pt_last_tile_handovers(pt_scene* scene);
+/* How many launches of this scene had their queue waiters give up — no tile finished or handed over for "queue_timeout_ms"
+ * (option, default 30 000) — although every tile was finished in the end. Not an error: waiters hold no tile, the frame is
+ * complete and exact; it says the device stalled (seen with several persistent kernels co-resident on one device). A launch
+ * that ends with unfinished tiles IS an error (-4). */
+int pt_queue_stalls(pt_scene* scene);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL
@@ -218,6 +223,7 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "sched_mask" 2^k-1    a wave looks at the queue every sched_mask + 1 iterations (31)
  *   "lpt_prio" 0|1|2      issue-priority steering: off / once no fresh tile is left / always (2)
  *   "persistent" 0|1      persistent waves on the tile queue (1)
+ *   "queue_timeout_ms" n  how long a wait on the tile queue may see no progress before the waiters leave (30 000)
  * Experimental options — variants that were built, proven bit-identical and measured SLOWER. The default
  * library does not contain their kernels (pt_has_experimental() == 0) and accepts only their "off" value, returning -3
  * otherwise; `make -C cudapathtracer_amd/csrc EXPERIMENTAL=1` builds them for the A/B:

@@ -205,6 +205,41 @@ def test_time_sliced_tile_queue(api, gpu_ready, sched):
         sc.close()
 
 
+def test_queue_waiters_that_give_up_do_not_fail_a_complete_frame(api, gpu_ready):
+    """The tile queue's waits are bounded (a logic error must not hang the GPU): a waiter that sees no progress for
+    "queue_timeout_ms" raises the queue's flag and every waiter leaves. Waiters hold no tile, so that is an error only if a tile
+    is left unfinished — a stalled device (round 3: four persistent kernels co-resident on one device, a 30 s stall, every tile
+    finished) costs the waiters, not the frame. With a timeout of zero the waiters leave at once: the frame is exact and the
+    stall is counted; with time slices of four iterations on top, a tile yielded to a queue nobody waits on any more may stay
+    unfinished, and THAT is reported (-4, never a silent partial frame)."""
+    g = np.load(os.path.join(GOLDEN, "cornell64_mis.npz"))
+    hs = api.HostScene(golden_case_scene(g))
+    w, h, spp, md = int(g["w"]), int(g["h"]), int(g["spp"]), int(g["max_depth"])
+    for opts in ({"queue_timeout_ms": 0}, {"queue_timeout_ms": 0, "onchip": 0, "waves_hbm": 0}, {"queue_timeout_ms": 0, "onchip": 0, "waves_hbm": 2}):
+        sc = api.Scene(hs, options=opts)
+        for _ in range(2):
+            col, _ = sc.render(hs.camera(), w, h, spp, md)
+            assert_bits_equal(col, g["colors"], "waiters gave up at once, %s" % opts)
+        assert sc.queue_stalls() >= 1 and sc.tile_handovers() == 0, (opts, sc.queue_stalls())
+        sc.close()
+    outcomes = set()
+    for opts in ({"queue_timeout_ms": 0, "slice_iters": 4, "sched_mask": 3}, {"queue_timeout_ms": 0, "slice_iters": 4, "sched_mask": 3, "onchip": 0, "waves_hbm": 2}):
+        sc = api.Scene(hs, options=opts)
+        try:
+            col, _ = sc.render(hs.camera(), w, h, spp, md)
+            assert_bits_equal(col, g["colors"], "complete although the waiters had left, %s" % opts)
+            outcomes.add("complete")
+        except api.PtError as e:
+            assert "incomplete" in str(e) and "tiles finished" in str(e), e
+            outcomes.add("incomplete")
+        sc.close()
+    assert outcomes <= {"complete", "incomplete"} and outcomes
+    sc = api.Scene(hs)                                     # the default: 30 s, nobody gives up on a healthy device
+    col, _ = sc.render(hs.camera(), w, h, spp, md)
+    assert_bits_equal(col, g["colors"], "default timeout")
+    assert sc.queue_stalls() == 0
+
+
 @pytest.mark.parametrize("knobs", [("0", "4", "0", "0", "2", "0", "512", "0"),      # everything off: a wave stays in each loop until its last lane
                                    ("0", "4", "15", "15", "2", "0", "4", "2"),     # loops left as soon as ONE lane is through, shadow rays traced in the bounce
                                    ("1", "1", "8", "8", "2", "0", "4", "2"),       # production shape, traversal left only for the last sixteenth
@@ -674,7 +709,7 @@ def test_options_api(api, gpu_ready):
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
     defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 10, "tri_keep": 8, "defer_shadow": 0,
-                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0, "wf_wide_wg": 1, "lean": 1}
+                "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0, "wf_wide_wg": 1, "lean": 1, "queue_timeout_ms": 30000}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
     assert sc.flags()["flat"] and sc.flags()["onchip"] and not sc.flags()["culling"]
