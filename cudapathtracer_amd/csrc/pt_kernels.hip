@@ -56,9 +56,9 @@ __global__ void __launch_bounds__(256) rng_init_kernel(const uint32_t* __restric
     o[0] = v[0]; o[64] = v[1]; o[128] = v[2]; o[192] = v[3]; o[256] = v[4]; o[320] = d;
 }
 
-__global__ void queue_init_kernel(int* q, int mask, int nTiles) {
+__global__ void queue_init_kernel(int* q, int mask, int nTiles, unsigned long long timeout) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { q[0] = 0; q[1] = nTiles; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0; q[6] = 0; q[7] = 0; }
+    if (i == 0) { q[0] = 0; q[1] = nTiles; q[2] = 0; q[3] = 0; ((unsigned long long*)q)[2] = timeout; q[6] = 0; q[7] = 0; }
     if (i <= mask)
         ((unsigned long long*)(q + 8))[i] = i < nTiles ? (((unsigned long long)(unsigned)(i | kFreshBit) << 32) | (unsigned long long)(i + 1)) : (unsigned long long)i;
 }
@@ -240,7 +240,7 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
     int nBlocks = megakernel_blocks(P.tileCount, P.wgWaves);
     if (P.queue && P.gridBlocks > 0) {
         nBlocks = std::min(nBlocks, P.gridBlocks);
-        hipLaunchKernelGGL(queue_init_kernel, dim3((P.queueMask + 256) / 256), dim3(256), 0, stream, P.queue, P.queueMask, P.tileCount);
+        hipLaunchKernelGGL(queue_init_kernel, dim3((P.queueMask + 256) / 256), dim3(256), 0, stream, P.queue, P.queueMask, P.tileCount, P.queueTimeout);
     }
     dim3 grid(nBlocks), block(64 * P.wgWaves);
     const bool hbm = P.hbm != 0;                               // chosen by the host together with the spill layout

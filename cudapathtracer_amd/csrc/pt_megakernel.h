@@ -68,8 +68,8 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 
 // ---- tile queue of the persistent megakernel -------------------------------------------------
 // A bounded multi-producer / multi-consumer ring in global memory:
-//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] error, q[4] sum of remaining samples
-//   of the tiles being worked on, q[5] waves working; from q + 8: cap 64-bit slots {sequence, item}
+//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] error, q[4..5] the wait bound in ticks (64 bit, written by
+//   queue_init_kernel and read only by a waiter that sees no progress), q[6..7] what a waiter that gave up saw; from q + 8: cap 64-bit slots {sequence, item}
 //   (cap = mask + 1 >= tiles; Vyukov's scheme: slot p%cap holds sequence p+1 when push p is in it, and
 //   p+cap once pop p has taken it). It starts holding every tile once (kFreshBit). A wave that yields a
 //   tile at the end of a time slice pushes it back; a tile is in the ring at most once, so it cannot overflow.
@@ -90,7 +90,8 @@ constexpr unsigned long long kQueueTimeout = 3000000000ull;            // defaul
 #define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
-PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait, unsigned long long timeout) {
+PT_DEV unsigned long long queue_timeout(int* q) { return PT_QLOAD((unsigned long long*)q + 2); }
+PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
     int item = -1;
     if (lane == 0) {
         const unsigned pos = atomicAdd((unsigned*)&q[0], 1u);
@@ -113,7 +114,7 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait, unsig
                 const int progress = done + PT_QLOAD(&q[1]);
                 const unsigned long long now = wall_clock64();
                 if (progress != seen) { seen = progress; t0 = now; }
-                else if (now - t0 > timeout) {
+                else if (now - t0 > queue_timeout(q)) {
                     // what the waiter saw, for the host's error message: tiles finished and the wait in 2^20-tick units (q[6], q[7] are spare)
                     PT_QSTORE(&q[6], done); PT_QSTORE(&q[7], (int)((now - t0) >> 20));
                     PT_QSTORE(&q[3], 1);
@@ -125,14 +126,14 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait, unsig
     }
     return __builtin_amdgcn_readfirstlane(item);
 }
-PT_DEV void queue_push(int* q, int mask, int item, int lane, unsigned long long timeout) {
+PT_DEV void queue_push(int* q, int mask, int item, int lane) {
     if (lane == 0) {
         const unsigned pos = atomicAdd((unsigned*)&q[1], 1u);
         unsigned long long* slot = queue_slot(q, mask, pos);
         const unsigned long long t0 = wall_clock64();
         while ((unsigned)PT_QLOAD(slot) != pos) {
             if (PT_QLOAD(&q[3]) != 0) return;
-            if (wall_clock64() - t0 > timeout) { PT_QSTORE(&q[3], 2); return; }
+            if (wall_clock64() - t0 > queue_timeout(q)) { PT_QSTORE(&q[3], 2); return; }
             __builtin_amdgcn_s_sleep(4);
         }
         PT_QSTORE(slot, ((unsigned long long)(unsigned)item << 32) | (unsigned long long)(pos + 1u));
@@ -199,7 +200,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     int lt;
     bool fresh = true;
     if (P.queue) {
-        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0, P.queueTimeout);
+        const int item = queue_pop(P.queue, P.queueMask, P.tileCount, lane, !COUNT && P.sliceIters > 0);
         if (item < 0) break;
         fresh = (item & kFreshBit) != 0;
         lt = item & ~kFreshBit;
@@ -469,7 +470,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             // "memory" clobber keeps the compiler from moving the queue accesses above it; tests/test_isa.py checks the
             // instruction order in every non-counting instantiation.
             asm volatile("; PT_YIELD_STATE_STORED\n\ts_waitcnt vmcnt(0)" ::: "memory");
-            queue_push(P.queue, P.queueMask, lt, lane, P.queueTimeout);
+            queue_push(P.queue, P.queueMask, lt, lane);
         } else if (lane == 0) atomicAdd(&P.queue[2], 1);
     }
     if (COUNT) {

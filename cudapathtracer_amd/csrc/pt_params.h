@@ -99,7 +99,7 @@ struct KParams {
     int gridBlocks;                // persistent waves: workgroups that fill the chip (numCU x resident workgroups per CU)
     int* queue;                    // persistent waves: tile queue (pt_kernels.hip: queue_pop / queue_push); null = one tile per wave
     int queueMask;                 // ring capacity - 1 (power of two >= tileCount)
-    unsigned long long queueTimeout;   // ticks of the 100 MHz steady counter a wait on the queue may see no progress before it raises q[3] (default 30 s)
+    unsigned long long queueTimeout;   // ticks of the 100 MHz steady counter a wait on the queue may see no progress before it raises q[3] (default 30 s); the kernels read it from the queue header, where queue_init_kernel puts it
     int sliceIters;                // bounce iterations a wave keeps a tile once no fresh tile is left; 0 = until it is finished
     int sliceAlways;               // 1: slices from the first tile on (round-robin over all tiles), 0: only once no fresh tile is left
     int* left;                     // [tile][64] samples left per pixel of a yielded tile

@@ -24,7 +24,7 @@ def isa(tmp_path_factory):
     d = tmp_path_factory.mktemp("isa")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
     procs = []
-    for tu, extra in (("pt_mk_lds", ["-fno-slp-vectorize"]), ("pt_mk_hbm", [])):
+    for tu, extra in (("pt_mk_lds", ["-fno-slp-vectorize"]), ("pt_mk_hbm", ["-fno-slp-vectorize"])):
         out = str(d / (tu + ".s"))
         procs.append((out, subprocess.Popen(["hipcc"] + flags + extra + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, tu + ".hip")],
                                             stderr=subprocess.DEVNULL)))
@@ -110,19 +110,20 @@ def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
         no private segment at all;
       * the production kernel for scenes in HBM (8 waves per SIMD): 64 VGPRs, and a private segment that may not grow — its
         logic step peaks at ~125 live registers (no spill at a cap of 128, 31 spill sites at 96, 86 at 80, 159 at 64), the
-        price of eight waves per SIMD that measures 2 % FASTER than six with 86 (profiles/r03_ab_hbm_simple_shapes_*.log)."""
+        price of eight waves per SIMD that measures 2 % FASTER than six with 86 (profiles/r03_ab_hbm_simple_shapes_*.log). Without the
+        SLP vectorizer's packed pairs (Makefile, FLAGS_pt_mk_hbm) the segment is 220 B instead of 272 and the frame 3.4-3.8 % faster."""
     md = _metadata(isa)
     flat2 = md["_ZN2pt16megakernel_flat2ILi0ELb1ELb0EEEvNS_7KParamsE"]
     assert flat2["vgpr_count"] <= 128 and flat2["private_segment_fixed_size"] == 0 and flat2["vgpr_spill_count"] == 0, flat2
     share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1ELb0EEEvNS_7KParamsE"]    # megakernel<0, false, false, false, true, false, true, 1, false>: 4-wave REFILL SIMPLE
     assert share["vgpr_count"] <= 128 and share["private_segment_fixed_size"] == 0 and share["vgpr_spill_count"] == 0, share
     hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
-    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 268, hbm
+    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 220, hbm
     gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb0EEEvNS_7KParamsE"]                # generic bounce (all arms), REFILL, 6 waves per SIMD
-    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 380, gen
+    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 308, gen
     # the LEAN generic bounce (no leaf arms, no texture fetches: scenes of glass, mirrors, metals) against the all-arms one
     lean = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb1EEEvNS_7KParamsE"]
-    assert lean["vgpr_count"] == 80 and lean["private_segment_fixed_size"] <= 300, lean
+    assert lean["vgpr_count"] == 80 and lean["private_segment_fixed_size"] <= 240, lean
     lean4 = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb0ELi1ELb1EEEvNS_7KParamsE"]
     assert lean4["private_segment_fixed_size"] <= 56, lean4
     pair = md["_ZN2pt16megakernel_flat2ILi0ELb0ELb1EEEvNS_7KParamsE"]
