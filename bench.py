@@ -244,10 +244,13 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
         proj = {}
         for n in (2, 4, 8):
             trn = api.rank_tiles(w, h, 0, n)
-            tiles.zero_()
-            scene.render_tiles_device(cam, w, h, spp, md, tiles.data_ptr(), tiles=trn, stream=stream)
-            torch.cuda.synchronize()
-            proj[str(n)] = kernel_ms / scene.last_kernel_ms()
+            best = None
+            for _ in range(2):                                   # the first launch of a share's kernel also loads its code
+                tiles.zero_()
+                scene.render_tiles_device(cam, w, h, spp, md, tiles.data_ptr(), tiles=trn, stream=stream)
+                torch.cuda.synchronize()
+                best = scene.last_kernel_ms() if best is None else min(best, scene.last_kernel_ms())
+            proj[str(n)] = kernel_ms / best
         out["projected_scaling"] = dict(proj, note="one-GPU share measurements (kernel only, no gather): a projection, not a scaling curve")
     scene.close()
     return out, sinfo, info
