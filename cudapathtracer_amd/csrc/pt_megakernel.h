@@ -154,6 +154,7 @@ PT_DEV void megakernel_body(const KParams& P) {
     // of the resumable traversal, and the DEFER record holds the finished NEE term (PRE). True for SIMPLE and LEAN scenes and
     // for every scene the pair form of FLAT is launched on (pt_api.hip: noLeafTris).
     constexpr bool NOLEAF = SIMPLE || LEAN || (DEFER && FLAT);
+    constexpr bool TRISEL = PT_TRISEL_LEAN != 0 && LEAN && !SIMPLE && !ONCHIP && !COUNT;      // pt_trace.h: moller_trumbore_sel
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
     // ONCHIP kernels: the host guarantees that the bounce's records fit as well (pt_api.hip: `onchip`), so their address
@@ -386,14 +387,14 @@ PT_DEV void megakernel_body(const KParams& P) {
             }
 #endif
 #if !defined(PT_EXPERIMENTAL)
-            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF, TRISEL>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 2            // both bodies in the kernel, chosen per launch (A/B only: the second body costs registers)
             if (P.spec) trace_resume_spec<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
-            else trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            else trace_resume<COUNT, STACKN, ONCHIP, NOLEAF, TRISEL>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #elif PT_SPEC == 1
             trace_resume_spec<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep}, P.spec == 2);
 #else
-            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
+            trace_resume<COUNT, STACKN, ONCHIP, NOLEAF, TRISEL>(S, SC, st, rs, ps.o, ps.d, (nBusy * P.refillKeep) >> 4, thr, h, c, Keep{P.nodeKeep, P.triKeep});
 #endif
             PT_STAMP(1);
             continue;

@@ -112,6 +112,23 @@ PT_DEV bool slab(float mnx, float mny, float mnz, float mxx, float mxy, float mx
     return (tmx >= tmn) && (tmx > 0.0f);
 }
 
+// The hit test alone, for the FLAT leaf loops (they never use tmin): `tmax >= tmin && tmax > 0` as ONE compare. tmin's lower clamp
+// -1e30 becomes the smallest positive float: tmin' = max(tmin, FLT_TRUE_MIN), and tmax >= tmin' <=> tmax >= tmin && tmax > 0 (neither
+// side is ever NaN: v_min / v_max drop NaN operands and the clamps are finite; f32 denormals are preserved, .amdhsa_float_denorm_mode_32 3).
+// One v_cmp and one s_and less per test: the LDS-resident kernels run at the CU's instruction-issue ceiling.
+PT_DEV bool slab_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, V3 o, V3 inv) {
+    float tx1 = (mnx - o.x) * inv.x, tx2 = (mxx - o.x) * inv.x;
+    float tmn = fmaxf_(1.401298464e-45f, fminf_(tx1, tx2));
+    float tmx = fminf_(1e30f, fmaxf_(tx1, tx2));
+    float ty1 = (mny - o.y) * inv.y, ty2 = (mxy - o.y) * inv.y;
+    tmn = fmaxf_(tmn, fminf_(ty1, ty2));
+    tmx = fminf_(tmx, fmaxf_(ty1, ty2));
+    float tz1 = (mnz - o.z) * inv.z, tz2 = (mxz - o.z) * inv.z;
+    tmn = fmaxf_(tmn, fminf_(tz1, tz2));
+    tmx = fminf_(tmx, fmaxf_(tz1, tz2));
+    return tmx >= tmn;
+}
+
 // triangleIntersect (integratorUtilities.cuh:8-42) on a packed triangle.
 PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u, float& v) {
     V3 h = cross(d, e2);
@@ -126,12 +143,72 @@ PT_DEV bool moller_trumbore(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u,
     return ((u >= 0.0f) && (v >= 0.0f) && (u + v <= 1.0f)) && t > 0.0f;
 }
 
+// The same test without a divergent branch (trace_resume<..., TRISEL>: the LEAN general bounce for scenes in HBM, +4 % on the glass
+// blob; the SIMPLE kernel at 64 VGPRs loses 1-6 % to it and keeps the branches, profiles/r03_ab_scalar_lean.log): the
+// degenerate-triangle exit, the range test of the exact reciprocal and the four acceptance tests are lane masks combined at the
+// end; the full division only runs when some lane of the wave has |a| > 1e30 (wave-uniform, practically never). Same value of
+// (ok, t, u, v) whenever ok — the callers read t, u, v only then.
+PT_DEV bool moller_trumbore_sel(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float& u, float& v) {
+    V3 h = cross(d, e2);
+    float a = dot(h, e1);
+    const float m = __builtin_fabsf(a);
+    const float r0 = __builtin_amdgcn_rcpf(a);
+    float f = __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);          // rcp_exact's fast path: exact for 1e-12 <= |a| <= 1e30
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m > 1.0e30f) != 0ull, 0)) f = m > 1.0e30f ? 1.0f / a : f;
+    V3 s = o - v0;
+    u = f * dot(s, h);
+    V3 q = cross(s, e1);
+    v = f * dot(d, q);
+    t = f * dot(e2, q);
+    return (m >= 1e-12f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
+}
+
 // ONCHIP (template flag of the traversals): every PNode and PTri is in the LDS scene cache and the stack
 // fits its LDS part — Cornell-class scenes. The loops then carry no global-memory path and no branch for it.
+#ifndef PT_NODE_OVERLAP
+#define PT_NODE_OVERLAP 1
+#endif
+#ifndef PT_TRISEL_LEAN
+#define PT_TRISEL_LEAN 1
+#endif
 struct NodeData { f4v a, b, c, d; };
 template <bool ONCHIP = false>
 PT_DEV NodeData load_node(const DeviceScene& S, const SceneCache& C, int32_t i) {
     NodeData n;
+#if PT_NODE_OVERLAP
+    if (!ONCHIP) {
+        // Both halves of the wave in flight at once: the lanes whose node is beyond the LDS copy of the tree top issue their four
+        // global loads, the others their four LDS reads INTO THE SAME REGISTERS, then one wait for both counters. Written by hand
+        // because the compiler puts `s_waitcnt vmcnt(0)` between the two groups (it sees two writers of one register; the lanes
+        // are disjoint, the hardware has no such hazard), which adds the LDS round trip to every global one.
+        const uint32_t la = (uint32_t)(uintptr_t)C.nodes + (uint32_t)i * 64u;
+        const f4v* gp = reinterpret_cast<const f4v*>(S.nodes + i);
+        unsigned long long sv;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "v_cmp_le_i32 vcc, %[nn], %[i]\n\t"
+            "s_and_b64 exec, %[sv], vcc\n\t"
+            "s_cbranch_execz .Lng%=\n\t"
+            "global_load_dwordx4 %[a], %[gp], off\n\t"
+            "global_load_dwordx4 %[b], %[gp], off offset:16\n\t"
+            "global_load_dwordx4 %[c], %[gp], off offset:32\n\t"
+            "global_load_dwordx4 %[d], %[gp], off offset:48\n\t"
+            ".Lng%=:\n\t"
+            "s_andn2_b64 exec, %[sv], vcc\n\t"
+            "s_cbranch_execz .Lnl%=\n\t"
+            "ds_read_b128 %[a], %[la]\n\t"
+            "ds_read_b128 %[b], %[la] offset:16\n\t"
+            "ds_read_b128 %[c], %[la] offset:32\n\t"
+            "ds_read_b128 %[d], %[la] offset:48\n\t"
+            ".Lnl%=:\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)"
+            : [a] "=&v"(n.a), [b] "=&v"(n.b), [c] "=&v"(n.c), [d] "=&v"(n.d), [sv] "=&s"(sv)
+            : [i] "v"(i), [nn] "s"(C.nNodes), [la] "v"(la), [gp] "v"(gp)
+            : "vcc", "memory");
+        return n;
+    }
+#endif
     if (ONCHIP || i < C.nNodes) {
         lds_cf4* p = C.nodes + i * 4;
         n.a = p[0]; n.b = p[1]; n.c = p[2]; n.d = p[3];
@@ -699,13 +776,12 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64((hasExt && !inv_is_regular(invE)) || (hasShadow && !inv_is_regular(invS))) == 0ull) {
         for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes, both rays (see inv_is_regular)
             const LeafBox L = leaf_box(leaves, k);                // through the scalar cache: SGPR operands of the slab tests
-            float t0;
-            const bool eH = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, eo, invE, t0) && hasExt;
-            const bool sH = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, so, invS, t0) && hasShadow;
-            const int first = L.first, cnt = L.count;
-            const uint64_t m = (~0ull >> (64 - cnt)) << (uint32_t)first;
+            const bool eH = slab_hit(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, eo, invE);
+            const bool sH = slab_hit(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, so, invS);
+            const uint64_t m = ((1ull << (uint32_t)L.count) - 1ull) << (uint32_t)L.first;      // s_bfm_b64 (a leaf of a tree with two or more leaves holds < 64 triangles)
             tmE |= eH ? m : 0ull; tmS |= sH ? m : 0ull;
         }
+        tmE = hasExt ? tmE : 0ull; tmS = hasShadow ? tmS : 0ull;     // (once, not per leaf)
     } else {
         uint64_t visE = hasExt ? 1ull << (uint32_t)S.rootRef : 0ull, visS = hasShadow ? 1ull << (uint32_t)S.rootRef : 0ull;
         for (int i = 0; i < nInternal; ++i) {                     // wave-uniform loop
@@ -782,8 +858,8 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
             rem &= rem - 1ull;
             const TriEdges q = load_tri_edges(C, ti);
             float t, u, v;
-            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
-            if (ok && (t < rmax)) {
+            const bool ok = moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
+            if (ok & (t < rmax)) {
                 if (l < 64) {
                     const uint64_t tb = (uint64_t)f2u(t) << 32;
                     __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -982,7 +1058,7 @@ PT_DEV void ray_start(const DeviceScene& S, Stack<N>& st, RayState& r, bool hasS
 }
 
 // (eo, ed): the lane's extension ray, needed when its shadow ray ends inside this call.
-template <bool COUNT, int N, bool ONCHIP, bool NOLEAF = false>
+template <bool COUNT, int N, bool ONCHIP, bool NOLEAF = false, bool TRISEL = false>
 PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st, RayState& r, V3 eo, V3 ed, int minBusy,
                          V3& thr, Hit& h, Ctr& c, Keep k = Keep{0, 0}) {
     typedef LoopExit<ONCHIP> X;
@@ -1035,6 +1111,20 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
             if (COUNT) c.tris++;
             PT_UTIL_STEP(c, 2);
             float t, u, v;
+            if constexpr (TRISEL && NOLEAF && !COUNT && !PT_OCCL_BOOL) {
+                // select form: no divergent branch in the test or in what follows it (moller_trumbore_sel)
+                const bool hitOk = moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v) & (t < max_t);
+                const bool sh = isShadow & hitOk, upd = !isShadow & hitOk & (t < h.t);
+                occlBits |= sh ? kRayOccluded : 0u;
+                occluded = sh;
+                h.t = upd ? t : h.t; h.u = upd ? u : h.u; h.v = upd ? v : h.v;
+                h.tri = upd ? (int32_t)(idx & 0x7fffffffu) : h.tri;
+                h.material = upd ? f2i(q.e.z) : h.material;
+                ti++;
+                more = !(idx & 0x80000000u) & !occluded;
+                if (X::tri && more && lanes_here() <= keepT) break;
+                continue;
+            }
             bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (isShadow) {
                 if (ok && (t < max_t)) {

@@ -118,9 +118,9 @@ def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
     share = md["_ZN2pt10megakernelILi0ELb0ELb0ELb0ELb1ELb0ELb1ELi1ELb0EEEvNS_7KParamsE"]    # megakernel<0, false, false, false, true, false, true, 1, false>: 4-wave REFILL SIMPLE
     assert share["vgpr_count"] <= 128 and share["private_segment_fixed_size"] == 0 and share["vgpr_spill_count"] == 0, share
     hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
-    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 220, hbm
+    assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 224, hbm
     gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb0EEEvNS_7KParamsE"]                # generic bounce (all arms), REFILL, 6 waves per SIMD
-    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 308, gen
+    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 316, gen
     # the LEAN generic bounce (no leaf arms, no texture fetches: scenes of glass, mirrors, metals) against the all-arms one
     lean = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb1EEEvNS_7KParamsE"]
     assert lean["vgpr_count"] == 80 and lean["private_segment_fixed_size"] <= 240, lean
@@ -162,3 +162,32 @@ def test_traversal_loops_of_the_kernels_for_scenes_in_hbm_hold_no_spill_code(isa
         assert len(loops) >= 2, (name, loops)
         assert all(ls == 0 and sc == 0 for (_, _, ls, sc) in loops), (name, loops)
         assert min(n for (n, _, _, _) in loops) <= 120, (name, loops)          # the node loop: 116 instructions, 62 of them VALU
+
+
+def test_node_fetch_keeps_lds_and_global_reads_in_flight_together(isa):
+    """pt_trace.h: load_node (PT_NODE_OVERLAP): the lanes whose node is in HBM issue their four global loads, the lanes whose node
+    is in the LDS copy of the tree top their four LDS reads into the SAME registers, and only then the wave waits — the compiler's own
+    if/else puts `s_waitcnt vmcnt(0)` between the two groups. Checked on the code as built: no wait between the first global load
+    and the last LDS read of a fetch, one wait for both counters after it."""
+    fns = _functions(isa)
+    checked = 0
+    for name, body in fns.items():
+        if "megakernel_hbm" not in name:
+            continue
+        lines = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith(";")]
+        for i, ln in enumerate(lines):
+            if not re.match(r"\.Lng\d+:", ln):
+                continue
+            # back to the fetch's first instruction, forward to its wait
+            j = i
+            while not lines[j].startswith("s_mov_b64") or "exec" not in lines[j]:
+                j -= 1
+            k = i
+            while not lines[k].startswith("s_waitcnt"):
+                k += 1
+            block = lines[j:k + 1]
+            assert sum(1 for x in block if x.startswith("global_load_dwordx4")) == 4, (name, block)
+            assert sum(1 for x in block if x.startswith("ds_read_b128")) == 4, (name, block)
+            assert sum(1 for x in block if x.startswith("s_waitcnt")) == 1 and re.match(r"s_waitcnt\s+vmcnt\(0\)\s+lgkmcnt\(0\)", block[-1]), (name, block)
+            checked += 1
+    assert checked >= 8, checked
