@@ -47,13 +47,18 @@ PT_DEV float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
 #endif
 PT_DEV float rcp_exact(float a) {
 #if PT_FAST_RCP
+    // The range test is wave-uniform, not per lane: every lane computes the fast form, and only when some lane of the wave is
+    // outside its range (practically never) do the lanes run the full division and those lanes take it. A per-lane `if` costs an
+    // exec-mask save / restore and two skip branches at every call site, and the kernels are bound by instruction issue.
     const float m = __builtin_fabsf(a);
-    if (m >= 1e-12f && m <= 1.0e30f) {
-        const float r0 = __builtin_amdgcn_rcpf(a);
-        return __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);
-    }
-#endif
+    const float r0 = __builtin_amdgcn_rcpf(a);
+    float r = __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);
+    const bool inRange = m >= 1e-12f && m <= 1.0e30f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0ull, 0)) r = inRange ? r : 1.0f / a;
+    return r;
+#else
     return 1.0f / a;
+#endif
 }
 PT_DEV float rsqrt_(float x) { return rcp_exact(__builtin_sqrtf(x)); }    // rsqrtf := 1/sqrt, both correctly rounded
 PT_DEV V3 normalize(V3 v) { float il = rsqrt_(dot(v, v)); return V3{v.x * il, v.y * il, v.z * il}; }   // util.cuh:128-131

@@ -113,8 +113,10 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
                 // slice, so the end of a long frame (fewer tiles left than waves) is not a timeout
                 const int progress = done + PT_QLOAD(&q[1]);
                 const unsigned long long now = wall_clock64();
-                if (progress != seen) { seen = progress; t0 = now; }
-                else if (now - t0 > queue_timeout(q)) {
+                const bool moved = progress != seen;
+                if (moved) { seen = progress; t0 = now; }
+                const unsigned long long tmo = queue_timeout(q);
+                if (tmo == 0ull || (!moved && now - t0 > tmo)) {                // (a bound of zero: no waiting at all — the give-up path, deterministically, for the tests)
                     // what the waiter saw, for the host's error message: tiles finished and the wait in 2^20-tick units (q[6], q[7] are spare)
                     PT_QSTORE(&q[6], done); PT_QSTORE(&q[7], (int)((now - t0) >> 20));
                     PT_QSTORE(&q[3], 1);

@@ -160,7 +160,8 @@ PT_DEV bool moller_trumbore_sel(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float
     V3 q = cross(s, e1);
     v = f * dot(d, q);
     t = f * dot(e2, q);
-    return (m >= 1e-12f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
+    // (u >= 0 && v >= 0 as one compare on v_min: it drops a NaN operand, but then u + v is NaN and the next test fails anyway)
+    return (m >= 1e-12f) & (fminf_(u, v) >= 0.0f) & (u + v <= 1.0f) & (t > 0.0f);
 }
 
 // ONCHIP (template flag of the traversals): every PNode and PTri is in the LDS scene cache and the stack
@@ -774,6 +775,7 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     uint64_t tmE = 0ull, tmS = 0ull;
     if (S.rootRef < 0) { const uint64_t all = ~0ull >> (64 - S.nTris); tmE = hasExt ? all : 0ull; tmS = hasShadow ? all : 0ull; }
     else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64((hasExt && !inv_is_regular(invE)) || (hasShadow && !inv_is_regular(invS))) == 0ull) {
+        _Pragma("unroll 2")
         for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes, both rays (see inv_is_regular)
             const LeafBox L = leaf_box(leaves, k);                // through the scalar cache: SGPR operands of the slab tests
             const bool eH = slab_hit(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, eo, invE);
@@ -830,8 +832,6 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     kLo[lane] = ~0ull; kHi[lane] = ~0ull;
     wave_lds_sync();
     const int per = (total + 63) >> 6;
-    int p = lane * per;
-    const int pEnd = (p + per < total) ? p + per : total;
     int l = 0;
     uint64_t rem = 0ull;
     V3 ro = v3(0.0f), rd = v3(0.0f);
@@ -842,7 +842,12 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
         rd = v3(__builtin_bit_cast(float, Wd[3 * 128 + v]), __builtin_bit_cast(float, Wd[4 * 128 + v]), __builtin_bit_cast(float, Wd[5 * 128 + v]));
         rmax = __builtin_bit_cast(float, Wd[6 * 128 + v]);
     };
-    if (p < pEnd) {
+    if (per > 0) {                                                // wave-uniform
+        // Every lane runs exactly `per` tests, [p, p + per): the last lanes start early enough to stay inside [0, total) and repeat
+        // tests of their neighbours — a repeated test changes nothing (same keys into the same minima, the same flag), and the loop
+        // below needs no per-lane guard: this kernel runs at the CU's instruction-issue ceiling, a guard is three instructions per trip.
+        int p = lane * per;
+        p = p < total - per ? p : total - per;
         l = p >= totalE ? 64 : 0;                                  // owner of test p among the 128 entries: the shadow rays' tests start at totalE,
         for (int sft = 32; sft; sft >>= 1) { const int cand = l + sft; if (Wd[kPre + cand] <= p) l = cand; }     // six dependent LDS reads for the rest
         fetch(l);
@@ -852,21 +857,18 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
     Wd[kOcc + lane] = 0;                                          // ... their first 64 words now hold the shadow rays' "occluded" flags
     wave_lds_sync();
     for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
-        if (p < pEnd) {
-            while (rem == 0ull) { l++; fetch(l); }                // next ray that has tests (there is one: p < total)
-            const int ti = __builtin_ctzll(rem);
-            rem &= rem - 1ull;
-            const TriEdges q = load_tri_edges(C, ti);
-            float t, u, v;
-            const bool ok = moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
-            if (ok & (t < rmax)) {
-                if (l < 64) {
-                    const uint64_t tb = (uint64_t)f2u(t) << 32;
-                    __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(63 - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else Wd[kOcc + (l - 64)] = 1;                    // NOLEAF: any hit below max_t ends the shadow ray (BVHShadowRay returns 0)
-            }
-            p++;
+        while (rem == 0ull) { l++; fetch(l); }                    // next ray that has tests (there is one: the lane's tests end below `total`)
+        const int ti = __builtin_ctzll(rem);
+        rem &= rem - 1ull;
+        const TriEdges q = load_tri_edges(C, ti);
+        float t, u, v;
+        const bool ok = moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
+        if (ok & (t < rmax)) {
+            if (l < 64) {
+                const uint64_t tb = (uint64_t)f2u(t) << 32;
+                __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(63 - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else Wd[kOcc + (l - 64)] = 1;                        // NOLEAF: any hit below max_t ends the shadow ray (BVHShadowRay returns 0)
         }
     }
     wave_lds_sync();
@@ -911,7 +913,7 @@ PT_DEV void trace_pair_flat(const DeviceScene& S, const SceneCache& C, Stack<N>&
             }
             const TriData q = load_tri<true>(S, C, win);
             float t, u, v;
-            moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), eo, ed, t, u, v);
+            moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), eo, ed, t, u, v);     // (a known hit: same t, u, v)
             hit.t = t; hit.u = u; hit.v = v;
             hit.tri = (int32_t)(f2u(q.e.y) & 0x7fffffffu);
             hit.material = f2i(q.e.z);
