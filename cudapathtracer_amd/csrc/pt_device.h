@@ -45,11 +45,15 @@ PT_DEV float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
 #ifndef PT_FAST_RCP
 #define PT_FAST_RCP 1
 #endif
+#ifndef PT_RCP_UNIFORM
+#define PT_RCP_UNIFORM 1
+#endif
 PT_DEV float rcp_exact(float a) {
-#if PT_FAST_RCP
+#if PT_FAST_RCP && PT_RCP_UNIFORM
     // The range test is wave-uniform, not per lane: every lane computes the fast form, and only when some lane of the wave is
     // outside its range (practically never) do the lanes run the full division and those lanes take it. A per-lane `if` costs an
-    // exec-mask save / restore and two skip branches at every call site, and the kernels are bound by instruction issue.
+    // exec-mask save / restore and two skip branches at every call site, and the LDS-resident kernels are bound by instruction
+    // issue (pt_mk_hbm.hip keeps the per-lane form below: it measures 0.7-1.0 % faster there).
     const float m = __builtin_fabsf(a);
     const float r0 = __builtin_amdgcn_rcpf(a);
     float r = __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);
@@ -57,6 +61,13 @@ PT_DEV float rcp_exact(float a) {
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inRange) != 0ull, 0)) r = inRange ? r : 1.0f / a;
     return r;
 #else
+#if PT_FAST_RCP
+    const float m = __builtin_fabsf(a);
+    if (m >= 1e-12f && m <= 1.0e30f) {
+        const float r0 = __builtin_amdgcn_rcpf(a);
+        return __builtin_fmaf(r0, __builtin_fmaf(-a, r0, 1.0f), r0);
+    }
+#endif
     return 1.0f / a;
 #endif
 }

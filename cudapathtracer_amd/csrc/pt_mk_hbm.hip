@@ -1,7 +1,12 @@
 // pt_mk_hbm.hip — megakernel instantiations for scenes in HBM: megakernel_hbm (6 waves per SIMD, 12-wave workgroups
 // sharing a 44 KB copy of the top of the tree; loop exits, REFILL, opt-in culling) and the general 4-wave kernel
 // (launches with too few tiles to fill its waves; -DPT_EXPERIMENTAL builds add the A/B instantiations of DESIGN.md §6).
-// Latency-bound; built with the default flags (the SLP vectorizer is worth +1 % here).
+// Built without the SLP vectorizer since round 3 (Makefile: at 64 VGPRs its packed pairs cost spills, -3.4 / -3.8 %), and with the
+// per-lane range test in rcp_exact: the wave-uniform form that pays for the issue-bound LDS-resident kernels measures 0.7-1.0 %
+// slower here (profiles/r03_ab_rcp_uniform_hbm.log).
+#ifndef PT_RCP_UNIFORM
+#define PT_RCP_UNIFORM 0
+#endif
 #include "pt_megakernel.h"
 
 namespace pt {

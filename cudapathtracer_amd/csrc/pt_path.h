@@ -265,7 +265,7 @@ PT_DEV bool bounce_core(const DeviceScene& S, Rng& rng, V3& o, V3& d, V3& beta, 
             float t = length(s2l) - kEps;
             {
                 float tt, uu, vv;
-                if (moller_trumbore(A, B - A, Cc - A, ro, wi, tt, uu, vv)) t = tt;
+                if ((PT_RCP_UNIFORM ? moller_trumbore_sel : moller_trumbore)(A, B - A, Cc - A, ro, wi, tt, uu, vv)) t = tt;     // (branch-free in the issue-bound LDS-resident kernels)
             }
             const float maxt = t * (1.0f - kEps);
             V3 thr = v3(1.0f);
