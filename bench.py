@@ -220,6 +220,9 @@ def measure(ctx, workload, spp_override, steps, warmup, opts, variant, culling):
             rf["profile"] = {"file": "profiles/roofline_inputs.json", "workload": workload, "spp": spp, "source": entry.get("source")}
     if stale:
         rf["stale_profile"] = True                               # a PMC pass exists, but of other code: re-run tools/profile_round.sh
+    issue = RF.issue_block(entry, 8 if "hbm_simple" in kname else (6 if "megakernel_hbm" in kname else 4)) if variant == "megakernel" else None
+    if issue is not None:
+        rf["issue"] = issue                                      # every instruction class against the CU's measured issue ceiling
     rf["code_sha256"] = ctx["code_hashes"].get(kname)
     rf["traffic"] = RF.traffic_bytes(entry)
     rf["kernel"] = kname

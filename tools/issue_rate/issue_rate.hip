@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void spin(int iters, uint32_t* out) {
 
 template <int MODE>
 static void run(int iters, uint32_t* d, int cus, const char* what, int instPerIter) {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 4, 6, 8}) {
         const int blocks = cus * 4 * w;
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);

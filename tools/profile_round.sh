@@ -11,7 +11,7 @@ mkdir -p $out
 SQ="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_SALU"
 run_pmc() {  # workload spp name [more passes: one quoted counter list each]
   wl=$1; sp=$2; nm=$3; shift 3
-  bash tools/pmc_passes.sh $out/pmc_$nm $wl $sp "$SQ" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "$@"
+  bash tools/pmc_passes.sh $out/pmc_$nm $wl $sp "$SQ" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM" "$@"
   set -- $wl $sp $nm
   ms=$(python - <<PY
 import csv,glob

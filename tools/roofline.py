@@ -179,6 +179,30 @@ def l1_roofline(global_node_fetches, global_tri_tests, kernel_ms):
             "line_accesses_per_launch": lines}
 
 
+# What one CU issued per clock in tools/issue_rate/issue_rate.hip (profiles/r03_issue_rate_microbench.log; rates at the nominal 2.4 GHz):
+# the best instruction stream we could construct, by waves per SIMD. VALU alone: 1.68 (4 waves) / 1.75 (8); the scalar unit alone 0.95.
+ISSUE_CEILING = {4: 1.97, 6: 2.13, 8: 2.23}          # (those streams are three v_add per s_nop / s_waitcnt; of v_add + s_add + branches: 1.81 / 1.90 / 2.06)
+ISSUE_VALU_ALONE = {4: 1.68, 6: 1.78, 8: 1.80}
+ISSUE_SALU_ALONE = 0.95
+
+
+def issue_block(entry, waves_per_simd):
+    """Instructions of every class the profiled launch issued per clock and CU (SQ_INSTS*, clocks = GRBM_GUI_ACTIVE / 8 XCDs) next to
+    the ceilings of the issue-rate micro-benchmark at the kernel's waves per SIMD. None without the counters of that PMC pass."""
+    need = ("SQ_INSTS", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE")
+    if not entry or any(not entry.get(k) for k in need):
+        return None
+    clk = entry["GRBM_GUI_ACTIVE"] / 8.0 * CUS
+    per = lambda k: entry.get(k, 0.0) / clk
+    w = 8 if waves_per_simd >= 8 else (6 if waves_per_simd >= 6 else 4)
+    out = {"unit": "instructions / clock / CU", "total": per("SQ_INSTS"), "valu": per("SQ_INSTS_VALU"), "salu": per("SQ_INSTS_SALU"),
+           "branch": per("SQ_INSTS_BRANCH"), "lds": per("SQ_INSTS_LDS"), "vmem": per("SQ_INSTS_VMEM"), "smem": per("SQ_INSTS_SMEM"),
+           "waves_per_simd": waves_per_simd, "ceiling_total": ISSUE_CEILING[w], "ceiling_valu_alone": ISSUE_VALU_ALONE[w],
+           "ceiling_salu_alone": ISSUE_SALU_ALONE, "ceiling_source": "tools/issue_rate/issue_rate.hip, profiles/r03_issue_rate_microbench.log"}
+    out["frac_of_ceiling"] = out["total"] / out["ceiling_total"]
+    return out
+
+
 def ta_busy(entry):
     """Scenes in HBM: the fraction of its cycles a CU's texture addresser (the unit the L1 line rate belongs to) was busy in the
     profiled launch — TA_TA_BUSY summed over the CUs / TCP_GATE_EN1 summed over the CUs (the L1's clock). None without both."""
