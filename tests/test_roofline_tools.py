@@ -63,6 +63,11 @@ def test_committed_bench_line_follows_from_committed_inputs(capsys):
     assert b["secondary"][4]["config"]["variant"] == "wavefront"                      # BASELINE configs[4]: the divergence A/B
     assert set(b["projected_scaling"]) >= {"2", "4", "8"} and 1.0 < b["projected_scaling"]["8"] <= 8.0
     assert b["cpu_baseline"]["kind"] == "port" and b["cpu_baseline"]["cores"] >= 1
+    # round 3: every instruction class per clock and CU next to what a CU was measured to issue (tools/issue_rate): the headline kernel's
+    # VALU share of the nominal rate is `frac`; its total is close to that ceiling — which is why fewer instructions, not hidden latency, pay
+    iss = b["roofline"]["issue"]
+    assert iss["waves_per_simd"] == 4 and 0.85 < iss["frac_of_ceiling"] <= 1.0 and iss["valu"] < iss["ceiling_valu_alone"] and iss["salu"] < iss["ceiling_salu_alone"]
+    assert abs(iss["valu"] / 2.0 - b["roofline"]["frac"]) < 0.03            # the same VALU count against the profiled launch's own clocks
 
 
 def test_committed_counters_were_measured_on_the_built_kernels(api):

@@ -35,9 +35,10 @@ for ef in sorted(glob.glob(os.path.join(src, "entry_*.json"))):
     e = json.load(open(ef))
     e["source"] = os.path.relpath(out, ROOT)
     key = (e.get("workload"), e.get("spp"), e.get("kernel"), e.get("code_sha256"))
-    if key not in have:
-        inputs["entries"].append(e)
-        have.add(key)
+    if key in have:                                      # the same code measured again: the newer pass replaces the older one
+        inputs["entries"] = [x for x in inputs["entries"] if (x.get("workload"), x.get("spp"), x.get("kernel"), x.get("code_sha256")) != key]
+    inputs["entries"].append(e)
+    have.add(key)
     print("entry", name, e["kernel"], (e.get("code_sha256") or "")[:12], "kernel_ms", e.get("kernel_ms"))
 json.dump(inputs, open(os.path.join(dst, "roofline_inputs.json"), "w"), indent=1)
 print(len(inputs["entries"]), "entries in profiles/roofline_inputs.json")
