@@ -74,7 +74,7 @@ struct pt_scene {
     bool wavesHbmOk = PT_WAVES_HBM > 0;   // "waves_hbm" 0: scenes in HBM use the 4-waves-per-SIMD kernel too (A/B)
     int nodeKeep = 10, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
-    int refill = 1, refillKeep = 4;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
+    int refill = 1, refillKeep = 6;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)

@@ -708,7 +708,7 @@ def test_options_api(api, gpu_ready):
     finally:
         for k in ("PT_FLAT", "PT_CULL", "PT_ONCHIP"):
             del os.environ[k]
-    defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 4, "node_keep": 10, "tri_keep": 8, "defer_shadow": 0,
+    defaults = {"flat": 1, "onchip": 1, "waves_hbm": 1, "refill": 1, "refill_keep": 6, "node_keep": 10, "tri_keep": 8, "defer_shadow": 0,
                 "slice_iters": 512, "slice_always": 1, "sched_mask": 31, "lpt_prio": 2, "persistent": 1, "xcd_bands": 0, "culling": 0, "spec": 2, "simple": 1, "flat2": 1, "leaf_boxes": 1, "wide": 0, "compact": 0, "wf_wide_wg": 1, "lean": 1, "queue_timeout_ms": 30000}
     assert {k: sc.get_option(k) for k in defaults} == defaults
     sc.render(hs.camera(), 32, 32, 1, 4)
