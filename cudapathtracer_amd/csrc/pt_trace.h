@@ -622,10 +622,9 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
     else if (nLeaves > 0 && __builtin_amdgcn_ballot_w64(active && !inv_is_regular(inv)) == 0ull) {
         for (int k = 0; k < nLeaves; ++k) {                       // the leaves' own boxes (see inv_is_regular): wave-uniform loop
             const LeafBox L = leaf_box(leaves, k);               // through the scalar cache: SGPR operands of the slab test
-            float t0;
-            const bool hitL = slab(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, o, inv, t0) && active;
-            tm.or_if(hitL, Set::range(L.first, L.count));
+            tm.or_if(slab_hit(L.mnx, L.mny, L.mnz, L.mxx, L.mxy, L.mxz, o, inv), Set::range(L.first, L.count));
         }
+        if (!active) tm = Set::zero();                           // (once, not per leaf)
     } else {
         Set vis = Set::zero();
         if (active) vis = Set::range(S.rootRef, 1);
@@ -668,12 +667,14 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
         return m;
     };
     const int per = (total + 63) >> 6;
-    int p = lane * per;
-    const int pEnd = (p + per < total) ? p + per : total;
     int l = 0;
     Set rem = Set::zero();
     V3 ro = v3(0.0f), rd = v3(0.0f);
-    if (p < pEnd) {
+    if (per > 0) {                                                // wave-uniform
+        // every lane runs exactly `per` tests [p, p + per) inside [0, total): the last lanes repeat tests of their neighbours
+        // (idempotent) and the loop below needs no per-lane guard (see trace_pair_flat)
+        int p = lane * per;
+        p = p < total - per ? p : total - per;
         for (int s = 32; s; s >>= 1) { const int cand = l + s; if (Wd[kPre * 64 + cand] <= p) l = cand; }      // owner of test p: the last lane whose exclusive prefix is <= p
         rem = load_set(l);
         rem.keep_from_kth(p - Wd[kPre * 64 + l]);                                                             // its triangles from the (p - prefix)-th on
@@ -681,24 +682,21 @@ PT_DEV void trace_closest_flat(const DeviceScene& S, const SceneCache& C, bool a
         rd = v3(__builtin_bit_cast(float, Wd[3 * 64 + l]), __builtin_bit_cast(float, Wd[4 * 64 + l]), __builtin_bit_cast(float, Wd[5 * 64 + l]));
     }
     for (int trip = 0; trip < per; ++trip) {                      // wave-uniform loop
-        if (p < pEnd) {
-            while (!rem.any()) {                                  // next ray that has tests (there is one: p < total)
-                l++;
-                rem = load_set(l);
-                ro = v3(__builtin_bit_cast(float, Wd[0 * 64 + l]), __builtin_bit_cast(float, Wd[1 * 64 + l]), __builtin_bit_cast(float, Wd[2 * 64 + l]));
-                rd = v3(__builtin_bit_cast(float, Wd[3 * 64 + l]), __builtin_bit_cast(float, Wd[4 * 64 + l]), __builtin_bit_cast(float, Wd[5 * 64 + l]));
-            }
-            const int ti = rem.first();
-            rem.clear_first();
-            const TriEdges q = load_tri_edges(C, ti);
-            float t, u, v;
-            const bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
-            if (ok && (t < max_t)) {
-                const uint64_t tb = (uint64_t)f2u(t) << 32;           // t > 0: the bit pattern orders like the value
-                __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(kMaxI - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            p++;
+        while (!rem.any()) {                                      // next ray that has tests (there is one: the lane's tests end below `total`)
+            l++;
+            rem = load_set(l);
+            ro = v3(__builtin_bit_cast(float, Wd[0 * 64 + l]), __builtin_bit_cast(float, Wd[1 * 64 + l]), __builtin_bit_cast(float, Wd[2 * 64 + l]));
+            rd = v3(__builtin_bit_cast(float, Wd[3 * 64 + l]), __builtin_bit_cast(float, Wd[4 * 64 + l]), __builtin_bit_cast(float, Wd[5 * 64 + l]));
+        }
+        const int ti = rem.first();
+        rem.clear_first();
+        const TriEdges q = load_tri_edges(C, ti);
+        float t, u, v;
+        const bool ok = moller_trumbore_sel(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e2z), ro, rd, t, u, v);
+        if (ok & (t < max_t)) {
+            const uint64_t tb = (uint64_t)f2u(t) << 32;               // t > 0: the bit pattern orders like the value
+            __hip_atomic_fetch_min(kLo + l, (unsigned long long)(tb | (uint64_t)(uint32_t)ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(kHi + l, (unsigned long long)(tb | (uint64_t)(uint32_t)(kMaxI - ti)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     wave_lds_sync();
