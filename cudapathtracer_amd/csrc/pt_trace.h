@@ -172,6 +172,9 @@ PT_DEV bool moller_trumbore_sel(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float
 #ifndef PT_TRISEL_LEAN
 #define PT_TRISEL_LEAN 1
 #endif
+#ifndef PT_MT_SEL_RESUME
+#define PT_MT_SEL_RESUME 1
+#endif
 struct NodeData { f4v a, b, c, d; };
 template <bool ONCHIP = false>
 PT_DEV NodeData load_node(const DeviceScene& S, const SceneCache& C, int32_t i) {
@@ -1125,7 +1128,7 @@ PT_DEV void trace_resume(const DeviceScene& S, const SceneCache& C, Stack<N>& st
                 if (X::tri && more && lanes_here() <= keepT) break;
                 continue;
             }
-            bool ok = moller_trumbore(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
+            bool ok = ((PT_MT_SEL_RESUME && !ONCHIP && !COUNT) ? moller_trumbore_sel : moller_trumbore)(v3(q.a.x, q.a.y, q.a.z), v3(q.a.w, q.b.x, q.b.y), v3(q.b.z, q.b.w, q.e.x), o, d, t, u, v);
             if (isShadow) {
                 if (ok && (t < max_t)) {
                     uint32_t flags = f2u(q.e.w);
