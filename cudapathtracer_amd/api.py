@@ -116,6 +116,7 @@ def lib():
     L.pt_scene_flags.argtypes = [vp]
     L.pt_last_tile_handovers.argtypes = [vp]
     L.pt_queue_stalls.argtypes = [vp]
+    L.pt_debug_queue_header.argtypes = [vp, C.POINTER(C.c_int)]
     L.pt_set_culling.argtypes = [vp, i32]
     L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
     L.pt_get_option.argtypes = [vp, C.c_char_p, vp]
@@ -455,6 +456,14 @@ class Scene:
         n = lib().pt_last_tile_handovers(self.h)
         _check(min(n, 0), "pt_last_tile_handovers")
         return n
+
+    def queue_header(self):
+        """pt_debug_queue_header: the tile queue's 16 header words after the last queued launch (None: that launch used no queue)."""
+        out = (C.c_int * 16)()
+        rc = lib().pt_debug_queue_header(self.h, out)
+        if rc < 0:
+            _check(rc, "pt_debug_queue_header")
+        return list(out) if rc == 1 else None
 
     def queue_stalls(self):
         """pt_queue_stalls: launches whose queue waiters gave up although the frame was complete (not an error)."""

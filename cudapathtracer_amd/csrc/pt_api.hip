@@ -918,7 +918,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     if (s->persistent && !s->xcdBands) {
         int cap = 256;
         while (cap < t.count) cap <<= 1;
-        if (int r = s->queue.ensure((size_t)(8 + 2 * cap) * sizeof(int))) return r;
+        if (int r = s->queue.ensure((size_t)(kQueueHeader + 2 * cap) * sizeof(int))) return r;
         if (int r = s->left.ensure((size_t)t.count * 64 * sizeof(int))) return r;
         P.queue = (int*)s->queue.p; P.queueMask = cap - 1; P.left = (int*)s->left.p;
         P.gridBlocks = s->numCU * P.wavesPerSimd * 4 / wgWaves;      // n waves per SIMD = 4n waves per CU, in workgroups of wgWaves
@@ -1086,11 +1086,11 @@ static int queue_error(pt_scene* s) {
     int q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost) != hipSuccess) return fail(-2, "tile queue read-back failed");
     if (q[3] != 0) {
-        // A waiter saw no progress for the whole timeout and left. Waiters hold no tile: the frame is complete iff every tile has
-        // been finished (each wave counts its tile in q[2] after its last state store, and the kernel has ended). Only an
-        // unfinished tile — one yielded after the waiters had gone — is an error.
+        // A waiter saw no progress for the whole bound (bit 0: a stall, recorded; the waiters stayed), or gave up for good after four
+        // more (bit 1; bit 2: a push found no slot). The frame is complete iff every tile has been finished (each wave counts its tile
+        // in q[2] after its last state store, and the kernel has ended); only an unfinished tile is an error.
         if (q[2] >= s->lastLaunchTiles) { s->queueStalls++; return 0; }
-        return fail(-4, "megakernel tile queue timed out (code %d): %d of %d tiles finished, %d pops and %d pushes claimed; the first waiter gave up at %d finished after %.1f M ticks "
+        return fail(-4, "megakernel tile queue timed out (code %d): %d of %d tiles finished, %d pops and %d pushes claimed; the first stalled waiter saw %d finished after %.1f M ticks "
                         "of the device's steady counter without progress: the frame is incomplete", q[3], q[2], s->lastLaunchTiles, q[0], q[1], q[6], (double)q[7] * 1.048576);
     }
     return 0;
@@ -1104,6 +1104,16 @@ int pt_last_tile_handovers(pt_scene* s) {
     int q[4] = {0, 0, 0, 0};
     HIP_OK(hipMemcpy(q, s->queue.p, sizeof(q), hipMemcpyDeviceToHost));
     return std::max(0, q[1] - s->lastLaunchTiles);
+}
+
+// The 16 header words of the tile queue after the last queued launch (tests: the words' layout — q[4] / q[5], the issue-priority
+// steering's sums, are back at zero when the kernel has ended, q[8..9] hold the wait bound in ticks, q[3] the stall / error bits).
+int pt_debug_queue_header(pt_scene* s, int* out16) {
+    if (!s || !out16) return fail(-1, "null argument");
+    for (int i = 0; i < kQueueHeader; i++) out16[i] = 0;
+    if (!s->queue.p || s->variant != 0 || !s->lastLaunchQueued) return 0;
+    HIP_OK(hipMemcpy(out16, s->queue.p, kQueueHeader * sizeof(int), hipMemcpyDeviceToHost));
+    return 1;
 }
 
 // Launches of this scene whose queue waiters gave up (no progress for "queue_timeout_ms") although the frame was complete.

@@ -58,9 +58,9 @@ __global__ void __launch_bounds__(256) rng_init_kernel(const uint32_t* __restric
 
 __global__ void queue_init_kernel(int* q, int mask, int nTiles, unsigned long long timeout) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { q[0] = 0; q[1] = nTiles; q[2] = 0; q[3] = 0; ((unsigned long long*)q)[2] = timeout; q[6] = 0; q[7] = 0; }
+    if (i == 0) { q[0] = 0; q[1] = nTiles; q[2] = 0; q[3] = 0; q[4] = 0; q[5] = 0; q[6] = 0; q[7] = 0; ((unsigned long long*)q)[4] = timeout; }
     if (i <= mask)
-        ((unsigned long long*)(q + 8))[i] = i < nTiles ? (((unsigned long long)(unsigned)(i | kFreshBit) << 32) | (unsigned long long)(i + 1)) : (unsigned long long)i;
+        ((unsigned long long*)(q + kQueueHeader))[i] = i < nTiles ? (((unsigned long long)(unsigned)(i | kFreshBit) << 32) | (unsigned long long)(i + 1)) : (unsigned long long)i;
 }
 
 // -------------------------------------------------------------------------------------------

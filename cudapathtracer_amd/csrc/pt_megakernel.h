@@ -68,8 +68,10 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 
 // ---- tile queue of the persistent megakernel -------------------------------------------------
 // A bounded multi-producer / multi-consumer ring in global memory:
-//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] error, q[4..5] the wait bound in ticks (64 bit, written by
-//   queue_init_kernel and read only by a waiter that sees no progress), q[6..7] what a waiter that gave up saw; from q + 8: cap 64-bit slots {sequence, item}
+//   q[0] pops claimed, q[1] pushes claimed, q[2] tiles finished, q[3] stall / error word (below), q[4] sum of remaining samples
+//   of the tiles being worked on and q[5] waves working (issue-priority steering), q[6..7] what the first waiter that saw a stall
+//   saw, q[8..9] the wait bound in ticks (64 bit, written by queue_init_kernel, read only by a waiter that sees no progress);
+//   from q + kQueueHeader: cap 64-bit slots {sequence, item}
 //   (cap = mask + 1 >= tiles; Vyukov's scheme: slot p%cap holds sequence p+1 when push p is in it, and
 //   p+cap once pop p has taken it). It starts holding every tile once (kFreshBit). A wave that yields a
 //   tile at the end of a time slice pushes it back; a tile is in the ring at most once, so it cannot overflow.
@@ -80,17 +82,18 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 // at the memory side, never from a possibly stale cache line), slot and item travel in ONE 64-bit word, and
 // "state before the queue entry" is the wave waiting for its own stores: an explicit `s_waitcnt vmcnt(0)` between the
 // last state store and queue_push (see the end of megakernel_body; no fence emits it by itself).
-// Waits are bounded by a wall-clock timeout that raises q[3] and drains every waiter: a logic error must
-// surface as an error code, never as a hung GPU. The flag by itself is not an error (round 3): waiters that give up hold no
-// tile, and the frame is complete iff q[2] == tiles when the kernel has ended — which is what the host checks; a stall of
-// the device (seen once with four persistent kernels co-resident on one device inside a long-lived process) then costs
-// the waiters, not the frame. A tile yielded AFTER the waiters have left finds nobody to continue it: q[2] < tiles, an error.
+// Waits are bounded by the wall clock: a logic error must surface as an error code, never as a hung GPU. A waiter that sees no
+// progress for the bound RECORDS a stall (q[3] bit 0) and keeps waiting — a stall of the device (seen once: four persistent kernels
+// co-resident on one device inside a long-lived process, 30 s, every tile finished) must cost time, not tiles, and a waiter that left
+// would orphan whatever is pushed to the position it had claimed; from then on no wave yields its tile (the slices stop). Only after
+// four more bounds without progress does a waiter give up for good (bit 1; a push that cannot find its slot: bit 2): then every
+// waiter leaves, and the host reports the frame as incomplete if a tile is unfinished (q[2] < tiles) — never a silent partial frame.
 constexpr int kFreshBit = 1 << 30;
 constexpr unsigned long long kQueueTimeout = 3000000000ull;            // default: 30 s of the 100 MHz wall clock without any progress (KParams::queueTimeout)
 #define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + 8) + (pos & (unsigned)mask); }
-PT_DEV unsigned long long queue_timeout(int* q) { return PT_QLOAD((unsigned long long*)q + 2); }
+PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + kQueueHeader) + (pos & (unsigned)mask); }
+PT_DEV unsigned long long queue_timeout(int* q) { return PT_QLOAD((unsigned long long*)q + 4); }     // q[8..9]
 PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
     int item = -1;
     if (lane == 0) {
@@ -108,7 +111,8 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
             if (!mayWait) break;                                                // without time slices nothing is ever pushed
             if ((spin & 7) == 0) {
                 const int done = PT_QLOAD(&q[2]);
-                if (done >= nTiles || PT_QLOAD(&q[3]) != 0) break;              // frame finished, or somebody gave up
+                const int err = PT_QLOAD(&q[3]);
+                if (done >= nTiles || (err & 6) != 0) break;                    // frame finished, or a HARD give-up (2: a waiter, 4: a push)
                 // the clock only runs while nothing moves: every running wave pushes or finishes within one time
                 // slice, so the end of a long frame (fewer tiles left than waves) is not a timeout
                 const int progress = done + PT_QLOAD(&q[1]);
@@ -117,10 +121,17 @@ PT_DEV int queue_pop(int* q, int mask, int nTiles, int lane, bool mayWait) {
                 if (moved) { seen = progress; t0 = now; }
                 const unsigned long long tmo = queue_timeout(q);
                 if (tmo == 0ull || (!moved && now - t0 > tmo)) {                // (a bound of zero: no waiting at all — the give-up path, deterministically, for the tests)
-                    // what the waiter saw, for the host's error message: tiles finished and the wait in 2^20-tick units (q[6], q[7] are spare)
-                    PT_QSTORE(&q[6], done); PT_QSTORE(&q[7], (int)((now - t0) >> 20));
-                    PT_QSTORE(&q[3], 1);
-                    break;
+                    if (!(err & 1)) {
+                        // A stall: recorded (bit 0; what this waiter saw in q[6], q[7]: tiles finished, the wait in 2^20 ticks), and the wait
+                        // goes on — nobody abandons a claimed position for a stall, or a tile pushed to it later would be lost. From now on
+                        // no wave yields its tile any more (megakernel_body reads q[3] at a slice's end), so the frame finishes without them.
+                        PT_QSTORE(&q[6], done); PT_QSTORE(&q[7], (int)((now - t0) >> 20));
+                        atomicOr((unsigned*)&q[3], 1u);
+                        t0 = now;
+                    } else if (tmo == 0ull || now - t0 > 4ull * tmo) {          // four more bounds without progress: something is lost for good
+                        atomicOr((unsigned*)&q[3], 2u);
+                        break;
+                    }
                 }
             }
             __builtin_amdgcn_s_sleep(64);
@@ -134,8 +145,8 @@ PT_DEV void queue_push(int* q, int mask, int item, int lane) {
         unsigned long long* slot = queue_slot(q, mask, pos);
         const unsigned long long t0 = wall_clock64();
         while ((unsigned)PT_QLOAD(slot) != pos) {
-            if (PT_QLOAD(&q[3]) != 0) return;
-            if (wall_clock64() - t0 > queue_timeout(q)) { PT_QSTORE(&q[3], 2); return; }
+            if ((PT_QLOAD(&q[3]) & 6) != 0) return;
+            if (wall_clock64() - t0 > queue_timeout(q)) { atomicOr((unsigned*)&q[3], 4u); return; }
             __builtin_amdgcn_s_sleep(4);
         }
         PT_QSTORE(slot, ((unsigned long long)(unsigned)item << 32) | (unsigned long long)(pos + 1u));
@@ -312,7 +323,7 @@ PT_DEV void megakernel_body(const KParams& P) {
             const bool exhausted = PT_QLOAD(&P.queue[0]) >= P.tileCount;
             if (!COUNT && P.sliceIters > 0 && (exhausted || P.sliceAlways)) {
                 if (sliceEnd == 0x7fffffff) sliceEnd = itc + P.sliceIters;
-                else if (itc >= sliceEnd) stopStarting = true;
+                else if (itc >= sliceEnd) stopStarting = PT_QLOAD(&P.queue[3]) == 0;      // (after a stall was seen nobody yields any more: queue_pop)
             }
             if (lpt) {
                 int rem = samplesLeft + ((ps.flags & kInPath) ? 1 : 0);

@@ -28,6 +28,7 @@ constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
 #endif
 constexpr int kStackLdsHbm = PT_STACK_LDS_HBM;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
+constexpr int kQueueHeader = 16;     // ints of the tile queue before its slots (pt_megakernel.h: the queue's words)
 constexpr int kStackFlat2Rows = 24;   // 256-byte rows of LDS per wave of the pair form of FLAT (pt_trace.h: trace_pair_flat's scratch)
 constexpr int kCacheBytes = PT_CACHE_BYTES;
 // LDS-resident scenes also stage what the bounce reads — hit attributes (80 B per triangle), materials (96 B each) and lights

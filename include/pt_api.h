@@ -184,6 +184,11 @@ int pt_last_tile_handovers(pt_scene* scene);
  * complete and exact; it says the device stalled (seen with several persistent kernels co-resident on one device). A launch
  * that ends with unfinished tiles IS an error (-4). */
 int pt_queue_stalls(pt_scene* scene);
+/* Debug: the 16 header words of the tile queue after the last queued launch of this scene (1: copied, 0: the last launch used no
+ * queue). [0] pops claimed, [1] pushes claimed, [2] tiles finished, [3] stall / error bits (1: a waiter recorded a stall and kept
+ * waiting, 2: a waiter gave up for good, 4: a push found no slot), [4] / [5] the issue-priority steering's sums (zero once the kernel
+ * has ended), [6] / [7] what the first stalled waiter saw, [8..9] the wait bound in ticks of the 100 MHz steady counter. */
+int pt_debug_queue_header(pt_scene* scene, int* out16);
 /* Which instantiation the launcher picks for this scene: bit 0 = ONCHIP (whole packed scene in the LDS cache),
  * bit 1 = persistent waves on the tile queue, bit 2 = time slices on, bit 3 = the 6-waves-per-SIMD kernel for scenes in HBM
  * (as used by the last launch; it needs enough tiles), bit 4 = opt-in culling, bit 5 = the last launch used a REFILL

@@ -238,6 +238,20 @@ def test_queue_waiters_that_give_up_do_not_fail_a_complete_frame(api, gpu_ready)
     col, _ = sc.render(hs.camera(), w, h, spp, md)
     assert_bits_equal(col, g["colors"], "default timeout")
     assert sc.queue_stalls() == 0
+    # the queue's header words, each in its own place (round 3: the wait bound once sat on the words the issue-priority steering
+    # sums into, and a 1/8 share ran 12 % slower for it): everything claimed and finished, no stall, the steering's sums back at
+    # zero, the bound where the waiters read it
+    q = sc.queue_header()
+    tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    assert q[0] >= tiles and q[1] >= tiles and q[2] == tiles and q[3] == 0, q
+    assert q[4] == 0 and q[5] == 0, q
+    assert (q[8] & 0xffffffff) | (q[9] << 32) == 30000 * 100000, q
+    sc.close()
+    sc = api.Scene(hs, options={"lpt_prio": 0, "queue_timeout_ms": 7})
+    sc.render(hs.camera(), w, h, spp, md)
+    q = sc.queue_header()
+    assert q[2] == tiles and q[4] == 0 and q[5] == 0 and q[8] == 700000 and q[9] == 0, q
+    sc.close()
 
 
 @pytest.mark.parametrize("knobs", [("0", "4", "0", "0", "2", "0", "512", "0"),      # everything off: a wave stays in each loop until its last lane

@@ -120,7 +120,7 @@ def test_register_budgets_and_private_segments_of_the_timed_kernels(isa):
     hbm = md["_ZN2pt21megakernel_hbm_simpleILi0EEEvNS_7KParamsE"]
     assert hbm["vgpr_count"] == 64 and hbm["private_segment_fixed_size"] <= 224, hbm
     gen = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb0EEEvNS_7KParamsE"]                # generic bounce (all arms), REFILL, 6 waves per SIMD
-    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 316, gen
+    assert gen["vgpr_count"] == 80 and gen["private_segment_fixed_size"] <= 320, gen
     # the LEAN generic bounce (no leaf arms, no texture fetches: scenes of glass, mirrors, metals) against the all-arms one
     lean = md["_ZN2pt14megakernel_hbmILi0ELb0ELb0ELb1ELb0ELb1EEEvNS_7KParamsE"]
     assert lean["vgpr_count"] == 80 and lean["private_segment_fixed_size"] <= 240, lean
