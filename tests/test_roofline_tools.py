@@ -104,3 +104,22 @@ def test_every_committed_build_of_the_round_rendered_the_same_full_frames():
             if row.get("frame_sha"):
                 seen.setdefault(row["config"]["workload"], set()).add(row["frame_sha"])
     assert len(seen) == 5 and all(len(v) == 1 for v in seen.values()), seen       # rounds 2 and 3: kernels, layouts and node numbering changed, the frames did not
+
+
+def test_rocprof_average_of_the_headline_kernel_agrees_with_the_bench_line():
+    """profiles/<tag>_kernel_stats_headline.csv: rocprofv3 --kernel-trace --stats of `bench.py --no-secondary` (the headline's kernel
+    launched on whole frames only — the default command also launches it on 1/2, 1/4, 1/8 of the tiles for `projected_scaling`, which
+    pulls that summary's AVERAGE away from a frame's duration; its MAX is the frame). Both must agree with the line's kernel_ms."""
+    import csv
+    bench = _bench_files()[-1]
+    tag = os.path.basename(bench)[:-len("_bench.json")]
+    b = _latest_bench()
+    name, ms = b["roofline"]["kernel"], b["roofline"]["kernel_ms"]
+    head = os.path.join(os.path.dirname(bench), tag + "_kernel_stats_headline.csv")
+    full = os.path.join(os.path.dirname(bench), tag + "_kernel_stats.csv")
+    assert os.path.exists(head) and os.path.exists(full), (head, full)
+    row = [r for r in csv.DictReader(open(head)) if name in r["Name"]]
+    assert len(row) == 1 and int(row[0]["Calls"]) >= 3
+    assert abs(float(row[0]["AverageNs"]) * 1e-6 - ms) < 0.01 * ms, (row[0]["AverageNs"], ms)
+    row = [r for r in csv.DictReader(open(full)) if name in r["Name"]]
+    assert len(row) == 1 and abs(float(row[0]["MaxNs"]) * 1e-6 - ms) < 0.01 * ms, (row[0]["MaxNs"], ms)

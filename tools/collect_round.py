@@ -25,6 +25,9 @@ for f in glob.glob(os.path.join(src, "bench_*_fullspp.json")):
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "stats_headline", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats_headline.csv"))
 inputs = json.load(open(os.path.join(dst, "roofline_inputs.json")))
 have = {(e.get("workload"), e.get("spp"), e.get("kernel"), e.get("code_sha256")) for e in inputs["entries"]}
 for ef in sorted(glob.glob(os.path.join(src, "entry_*.json"))):

@@ -32,6 +32,9 @@ run_pmc cornell_mixed_1920x1080_1024spp_depth8_mis 1024 cornell_mixed           
 run_pmc blob82k_glass_1920x1080_1024spp_depth8_mis 128 blob_glass_spp128 "TA_TA_BUSY_sum" "TCP_GATE_EN1_sum"  # the general bounce, scene in HBM
 cp profiles/roofline_inputs.json $out/roofline_inputs.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -- python3 $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OLDPWD/$out/stats.log 2>&1 )
+# ... and of the headline alone (no secondaries, no share projections: those launch the headline's kernel on 1/2, 1/4, 1/8 of the tiles
+# and would pull its AVERAGE away from a frame's duration): this is the summary whose average must agree with bench.py's kernel_ms
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats_headline -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $OLDPWD/$out/stats_headline.log 2>&1 )
 python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.err
 python tools/roofline.py check $out/bench.json
 tail -c 400 $out/bench.json
