@@ -89,7 +89,6 @@ PT_DEV void path_finish(PathState& ps, V3& acc, bool defer) {
 // four more bounds without progress does a waiter give up for good (bit 1; a push that cannot find its slot: bit 2): then every
 // waiter leaves, and the host reports the frame as incomplete if a tile is unfinished (q[2] < tiles) — never a silent partial frame.
 constexpr int kFreshBit = 1 << 30;
-constexpr unsigned long long kQueueTimeout = 3000000000ull;            // default: 30 s of the 100 MHz wall clock without any progress (KParams::queueTimeout)
 #define PT_QLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define PT_QSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 PT_DEV unsigned long long* queue_slot(int* q, int mask, unsigned pos) { return (unsigned long long*)(q + kQueueHeader) + (pos & (unsigned)mask); }
