@@ -191,3 +191,10 @@ def test_node_fetch_keeps_lds_and_global_reads_in_flight_together(isa):
             assert sum(1 for x in block if x.startswith("s_waitcnt")) == 1 and re.match(r"s_waitcnt\s+vmcnt\(0\)\s+lgkmcnt\(0\)", block[-1]), (name, block)
             checked += 1
     assert checked >= 8, checked
+
+
+def test_f32_denormals_are_preserved_in_every_megakernel(isa):
+    """pt_trace.h: slab_hit folds `tmax > 0` into `tmax >= FLT_TRUE_MIN`; a build that flushed f32 denormals (-fgpu-flush-denormals-to-zero,
+    -Ofast) would turn that constant into 0 and accept tmax == 0. The kernel descriptors say what the waves run with."""
+    modes = re.findall(r"\.amdhsa_float_denorm_mode_32\s+(\d+)", isa)
+    assert len(modes) >= 28 and set(modes) == {"3"}, sorted(set(modes))
