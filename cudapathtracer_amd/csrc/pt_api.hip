@@ -850,7 +850,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
         compact = s->compactOk;
     }
 #endif
-    const int spillEntries = hbm ? std::max(0, (wide ? std::max(s->wideStackNeed, s->stackNeed) : s->stackNeed) - kStackLdsHbm) : s->ds.stackSpill;
+    const int spillEntries = hbm ? std::max(0, (wide ? std::max(s->wideStackNeed, s->stackNeed) : s->stackNeed) - (simpleHbm ? kStackLdsHbm : kStackLdsHbmGen)) : s->ds.stackSpill;
     const int wgWaves = hbm ? (simpleHbm ? kWgWavesHbmSimple : kWgWavesHbm) : (onchip ? scene_onchip_wg(s) : 4);
     int blocks = megakernel_blocks(t.count, wgWaves);
     if (spillEntries > 0)

@@ -247,7 +247,7 @@ hipError_t launch_megakernel(int integrator, bool count, bool syncShadow, const 
     const bool flat2 = P.flat == 3 && integrator == 0 && !count;
     const bool ldsScene = P.onchip && !hbm && (integrator == 2 || syncShadow || flat2);
     const bool simpleKernel = P.simple && !count && ((ldsScene && P.flat) || (!ldsScene && P.refill && !P.cull));      // the instantiations without medium stacks
-    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? kStackLdsHbm : (flat2 ? kStackFlat2 : kStackLds), P.wgWaves,
+    const unsigned lds = (unsigned)megakernel_lds_bytes(P.cacheNodes, P.cacheTris, hbm ? ((P.simple && P.refill && !count) ? kStackLdsHbm : kStackLdsHbmGen) : (flat2 ? kStackFlat2 : kStackLds), P.wgWaves,
                                                         ldsScene ? attr_cache_bytes(P.cacheAttrs, P.cacheMats, P.cacheLights) : 0, !simpleKernel);
     if (ldsScene) return launch_megakernel_lds(integrator, count, P, grid, block, lds, stream);
     return launch_megakernel_hbm(integrator, count, syncShadow, hbm, P, grid, block, lds, stream);

@@ -522,7 +522,7 @@ megakernel(KParams P) { megakernel_body<INTEG, COUNT, DEFER, ONCHIP, kStackLds, 
 
 template <int INTEG, bool COUNT, bool CULL, bool REFILL, bool SIMPLE = false, bool LEAN = false>
 __global__ void __launch_bounds__(64 * kWgWavesHbm) __attribute__((amdgpu_waves_per_eu(kWavesHbm)))
-megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbm, CULL, REFILL, false, SIMPLE, 1, 0, LEAN>(P); }
+megakernel_hbm(KParams P) { megakernel_body<INTEG, COUNT, false, false, kStackLdsHbmGen, CULL, REFILL, false, SIMPLE, 1, 0, LEAN>(P); }
 
 // FLAT for both rays of a lane (pt_trace.h: trace_pair_flat): scenes of at most 64 nodes / triangles none of which is a MAT_LEAF
 // (any hit occludes a shadow ray) and all of whose materials have a dispatch arm (the DEFER logic step is exact), MIS

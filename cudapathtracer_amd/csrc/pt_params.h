@@ -26,6 +26,11 @@ constexpr int kWavesHbm = PT_WAVES_HBM > 0 ? PT_WAVES_HBM : 6;
 #ifndef PT_STACK_LDS_HBM
 #define PT_STACK_LDS_HBM 8
 #endif
+#ifndef PT_STACK_LDS_HBM_GEN
+#define PT_STACK_LDS_HBM_GEN 12
+#endif
+constexpr int kStackLdsHbmGen = PT_STACK_LDS_HBM_GEN;     // ... of the GENERAL bounce's kernel (megakernel_hbm, six waves per SIMD): twelve entries measure +2.5 % on the glass blob over
+                                                           // eight (fewer stack entries in the global spill area for 64 cached nodes less); the SIMPLE kernel is flat from 6 to 12 (profiles/r03_ab_stack_rows_hbm.log)
 constexpr int kStackLdsHbm = PT_STACK_LDS_HBM;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
 constexpr int kQueueHeader = 16;     // ints of the tile queue before its slots (pt_megakernel.h: the queue's words)
@@ -47,7 +52,7 @@ constexpr int kAttrCacheBytes = PT_ATTR_CACHE_BYTES;
 #endif
 constexpr int kWgWavesHbm = (PT_WAVES_HBM > 0 && (kWavesHbm * 4) % PT_WG_WAVES_HBM == 0 && PT_WG_WAVES_HBM <= 16) ? PT_WG_WAVES_HBM : 4;
 constexpr int kCacheBytesHbm = kWgWavesHbm == 4 ? kCacheBytes
-                                                : ((160 * 1024) / ((kWavesHbm * 4) / kWgWavesHbm) - kWgWavesHbm * (kStackLdsHbm * 256 + kMediumMax * 64)) / 64 * 64;
+                                                : ((160 * 1024) / ((kWavesHbm * 4) / kWgWavesHbm) - kWgWavesHbm * (kStackLdsHbmGen * 256 + kMediumMax * 64)) / 64 * 64;
 
 // The SIMPLE instantiation of the kernel for scenes in HBM (pt_path.h: diffuse-only scenes) is a third of the generic
 // kernel's code and holds less state: it runs best at 8 waves per SIMD (64 VGPRs) in workgroups of 16 waves — one LDS copy
