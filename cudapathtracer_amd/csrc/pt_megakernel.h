@@ -166,7 +166,12 @@ PT_DEV void megakernel_body(const KParams& P) {
     // of the resumable traversal, and the DEFER record holds the finished NEE term (PRE). True for SIMPLE and LEAN scenes and
     // for every scene the pair form of FLAT is launched on (pt_api.hip: noLeafTris).
     constexpr bool NOLEAF = SIMPLE || LEAN || (DEFER && FLAT);
-    constexpr bool TRISEL = PT_TRISEL_LEAN != 0 && LEAN && !SIMPLE && !ONCHIP && !COUNT;      // pt_trace.h: moller_trumbore_sel
+    // (... and for the 4-wave SIMPLE kernel that small shares of a scene in HBM run — 128 VGPRs, chain-bound: 1/8 shares +4-5 %,
+    //  profiles/r03_shards_hbm_final.log; the 8-wave kernel at 64 VGPRs loses 1-6 % to it)
+#ifndef PT_TRISEL_SIMPLE4
+#define PT_TRISEL_SIMPLE4 1
+#endif
+    constexpr bool TRISEL = ((PT_TRISEL_LEAN != 0 && LEAN && !SIMPLE) || (PT_TRISEL_SIMPLE4 != 0 && SIMPLE && STACKN == kStackLds)) && !ONCHIP && !COUNT;      // pt_trace.h: moller_trumbore_sel
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nW = blockDim.x >> 6;      // nW waves share this workgroup's scene cache
     DeviceScene S = P.S;
     // ONCHIP kernels: the host guarantees that the bounce's records fit as well (pt_api.hip: `onchip`), so their address
