@@ -172,6 +172,9 @@ PT_DEV bool moller_trumbore_sel(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t, float
 #ifndef PT_TRISEL_LEAN
 #define PT_TRISEL_LEAN 1
 #endif
+#ifndef PT_SPILL_UNIFORM
+#define PT_SPILL_UNIFORM 1
+#endif
 #ifndef PT_MT_SEL_RESUME
 #define PT_MT_SEL_RESUME 1
 #endif
@@ -312,6 +315,22 @@ PT_DEV int32_t descend_node(const NodeData& n, int32_t cur, V3 o, V3 inv, Stack<
     bool hR = slab(n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, o, inv, tR);
     if (CULL) { hL = hL && !(tL > cullT); hR = hR && !(tR > cullT); }
     int32_t left = f2i(n.d.x), right = f2i(n.d.y);
+#if PT_SPILL_UNIFORM
+    if (!ONCHIP && !COUNT && !CULL && N == 16) {        // (kStackLds: the 4-wave kernels)
+        // the stack's spill test once per wave and trip instead of inside push and pop (the 4-wave kernels' sixteen LDS entries are
+        // rarely exceeded): no lane of the wave at the LDS part's edge -> the forms without a branch for the spill area
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(st.sp >= N - 1) == 0ull, 1)) {
+            if (hL && hR) {
+                bool leftNear = tL < tR;
+                st.template push<true>(leftNear ? right : left);
+                return leftNear ? left : right;
+            }
+            if (hL) return left;
+            if (hR) return right;
+            return st.sp > 0 ? st.template pop<true>() : kRefNone;
+        }
+    }
+#endif
     if (hL && hR) {
         bool leftNear = tL < tR;
         st.template push<ONCHIP>(leftNear ? right : left);
