@@ -75,6 +75,7 @@ struct pt_scene {
     int nodeKeep = 10, triKeep = 8;        // "node_keep" / "tri_keep" (pt_trace.h: LoopExit)
     int spec = 2;                          // -DPT_SPEC=1 builds only (A/B): speculative descent for shadow rays too (2) or closest-hit rays only (1)
     int refill = 1, refillKeep = 6;       // "refill" / "refill_keep": REFILL instantiation of the kernel for scenes in HBM (pt_trace.h: trace_resume)
+    bool refillKeepSet = false;           // (unset: the 4-wave kernel of small shares uses kRefillKeepSmall — it is chain-bound and wants its lanes back sooner)
     bool cull = false;                    // pt_set_culling / "culling": opt-in, not parity-exact by construction
     bool leafBoxes = true;                        // "leaf_boxes" 0: the FLAT kernels walk the nodes in lockstep instead of testing the leaves' own boxes (A/B)
     int flat2Wanted = 1; int lastLaunchFlat2 = 0;   // "flat2" 1 (default): SIMPLE FLAT scenes trace shadow + extension ray in one FLAT pass (DEFER logic step)
@@ -890,7 +891,7 @@ static int render_tiles(pt_scene* s, const pt_camera* cam, int w, int h, int spp
     P.S.stackSpill = spillEntries;
     P.cull = (s->cull && hbm) ? 1 : 0;
     P.refill = (s->refill && !deferred && !P.cull && !s->armless && (!onchip || s->refill == 2)) ? 1 : 0;   // 2: also the LDS-resident kernel (A/B)
-    P.refillKeep = s->refillKeep;
+    P.refillKeep = (hbm || s->refillKeepSet) ? s->refillKeep : kRefillKeepSmall;      // re-swept on the round's kernels: 6 for the 8-wave kernel, 10 for the 4-wave one (1/8 shares +5.5 % / +6 %, profiles/r03_shards_hbm_final.log)
     P.spec = s->spec;
     P.nodeKeep = s->nodeKeep; P.triKeep = s->triKeep;
     P.flat = 0;                                             // 1: FLAT with 64-bit masks, 2: with 128-bit masks
@@ -1161,7 +1162,7 @@ int pt_set_option(pt_scene* s, const char* name, int v) {
         case 1: s->onchipOk = v != 0; break;
         case 2: s->wavesHbmOk = v != 0 && PT_WAVES_HBM > 0; s->wavesHbmForce = s->wavesHbmOk && v == 2; break;
         case 3: s->refill = v; break;
-        case 4: s->refillKeep = v; break;
+        case 4: s->refillKeep = v; s->refillKeepSet = true; break;
         case 5: s->nodeKeep = v; break;
         case 6: s->triKeep = v; break;
         case 7: s->deferShadow = v != 0; break;

@@ -33,6 +33,7 @@ constexpr int kStackLdsHbmGen = PT_STACK_LDS_HBM_GEN;     // ... of the GENERAL 
                                                            // eight (fewer stack entries in the global spill area for 64 cached nodes less); the SIMPLE kernel is flat from 6 to 12 (profiles/r03_ab_stack_rows_hbm.log)
 constexpr int kStackLdsHbm = PT_STACK_LDS_HBM;    // its LDS stack entries per lane: 8 KB + 4 KB medium stacks + 12 KB cache = 24 KB, six workgroups per CU
 constexpr int kMediumMax = 16;    // mediumStack[16], deviceCode.cu:306
+constexpr int kRefillKeepSmall = 10;  // "refill_keep" of the 4-wave kernel for scenes in HBM while the option is unset (sixteenths of the busy lanes)
 constexpr int kQueueHeader = 16;     // ints of the tile queue before its slots (pt_megakernel.h: the queue's words)
 constexpr int kStackFlat2Rows = 24;   // 256-byte rows of LDS per wave of the pair form of FLAT (pt_trace.h: trace_pair_flat's scratch)
 constexpr int kCacheBytes = PT_CACHE_BYTES;

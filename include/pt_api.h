@@ -222,7 +222,7 @@ int pt_set_culling(pt_scene* scene, int on);
  *   "onchip" 0|1          LDS-resident instantiation when the scene fits (1)
  *   "waves_hbm" 0|1|2     the 6-waves-per-SIMD kernel for scenes in HBM: never / when the launch has enough tiles / always (1)
  *   "refill" 0|1          resumable traversal for scenes in HBM (1)
- *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (6, 10, 8; re-swept in round 3: profiles/r03_sweep_keep.log)
+ *   "refill_keep", "node_keep", "tri_keep" 0..15   loop-exit thresholds in sixteenths (6, 10, 8; re-swept in round 3: profiles/r03_sweep_keep.log — while "refill_keep" is unset the 4-wave kernel of small shares uses 10)
  *   "slice_iters" n       bounce iterations a wave keeps a tile before it queues it again, 0 = until finished (512)
  *   "slice_always" 0|1    time slices from the first tile on (1)
  *   "sched_mask" 2^k-1    a wave looks at the queue every sched_mask + 1 iterations (31)
